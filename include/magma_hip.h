@@ -1,0 +1,143 @@
+/* libmagma_hip.so -- C ABI of the MI355X (gfx950, FP64) implementation of MAGMA's multi-task-GP
+ * EM hot path. This is the drop-in boundary: what an R `.Call` shim, the
+ * Python ctypes host in `magma_amd/`, or any other FFI binds. Plain C types only.
+ *
+ * Reference = ArthurLeroy/MAGMA: CF = Computing_functions.R, MG = MAGMA.R. The reference has no
+ * FFI of its own (pure R closures); each entry point cites the R function whose body it
+ * replaces.
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers unless named `h_*`. `stream` is a hipStream_t
+ *    passed as void* (NULL = default stream). Calls enqueue work and return; results are valid
+ *    after magma_stream_sync(stream) (or any later work on the same stream).
+ *  - Return value: 0 = ok, >0 = error; magma_last_error() gives the message (thread-local).
+ *    A covariance that is not numerically positive definite is NOT an error: the per-matrix
+ *    `info` output is non-zero (index of the first bad pivot, LAPACK dpotrf style) and that
+ *    matrix's outputs are NaN / skipped; the host decides (the R code falls back to ginv,
+ *    CF:133,161,387).
+ *  - Ragged dataset: individual i owns rows off[i]..off[i+1]-1 of t / y / idx (timestamps
+ *    ascending within an individual, as the reference assumes: CF:74,95). idx[] is the int32
+ *    position of each timestamp in the sorted union grid (replaces the `paste0('X', t)` names of
+ *    CF:78,451,474). n_i <= 64.
+ *  - theta: per-individual (theta1, theta2, sigma) triples; theta_stride = 3, or 0 when every
+ *    individual shares one triple (the "common HP" case, CF:89-93).
+ *  - Dense matrices are Np x Np column-major with ld = Np = magma_pad(N) (N rounded up to a
+ *    multiple of 64); rows/cols >= N hold the identity. Vectors on the grid have length Np.
+ *  - One caller thread per stream; buffers must not be shared by concurrent calls.
+ */
+#ifndef MAGMA_HIP_H
+#define MAGMA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library / device plumbing (no counterpart in the reference) ---- */
+int magma_hip_version(void);
+const char* magma_last_error(void);
+int magma_pad(int N);
+size_t magma_workspace_bytes(int N); /* scratch needed by the dense entry points below */
+int magma_device_count(int* h_count);
+int magma_set_device(int device);
+int magma_dev_malloc(void** h_ptr, size_t bytes);
+int magma_dev_free(void* ptr);
+int magma_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream);
+int magma_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream);
+int magma_memset_zero(void* dst, size_t bytes, void* stream);
+int magma_stream_sync(void* stream);
+
+/* ---- (1) batched SE-kernel covariance ---- */
+/* kern_to_cov, tibble branch (CF:85-112): K_i = SE(t_i; theta_i) + sigma_i^2 I for every
+ * individual, written column-major at K_out + off2[i] (off2[i] = sum_{j<i} n_j^2). */
+int magma_kern_to_cov_batched(int M, const int64_t* off, const int64_t* off2, const double* t,
+                              const double* theta, int theta_stride, double* K_out, void* stream);
+/* kern_to_cov / kern_to_inv, vector branch (CF:66-81): K_0 on the union grid,
+ * diagonal exp(theta1) + sigma^2; A is Np x Np (padding = identity). */
+int magma_kern_to_cov_grid(int N, const double* grid, double theta1, double theta2, double sigma,
+                           double* A, void* stream);
+
+/* ---- (2) batched small-matrix factorisation / inverse / log-det ---- */
+/* kern_to_inv, tibble branch (CF:141-170), plus log|K_i| (dmvnorm's determinant, CF:27):
+ * one wavefront per matrix, K_i never written to memory. nmax >= max_i n_i. */
+int magma_kern_to_inv_batched(int M, int nmax, const int64_t* off, const int64_t* off2,
+                              const double* t, const double* theta, int theta_stride,
+                              double* Kinv_out, double* logdet_out, int* info_out, void* stream);
+
+/* ---- (3) E-step ---- */
+/* update_inv + update_mean over this rank's individuals (CF:440-478), fused with the
+ * construction and inversion of every K_i: P[idx,idx] += K_i^-1 (lower triangle), w[idx] +=
+ * K_i^-1 y_i, by FP64 atomics. P (Np x Np) and w (Np) must be zeroed by the caller; partial
+ * sums of several ranks are combined by the caller (all-reduce) before magma_estep_finish. */
+int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
+                        const int* idx, const double* theta, int theta_stride, int N, double* P,
+                        double* w, int* info_out, void* stream);
+/* Rest of e_step (CF:382,386-391) / posterior_mu (MG:118-128): K_0^-1 on the grid with
+ * `pen_diag` on the diagonal, P += K_0^-1, w += K_0^-1 m_0, cov = P^-1 (blocked MFMA Cholesky,
+ * in place in P, full symmetric), mean = cov w. m0: Np values. h_info: host int, LAPACK-style
+ * status of the two factorisations (0 ok; synchronises the stream). */
+int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                       const double* m0, double* P, double* w, double* mean_out, void* work,
+                       int* h_info, void* stream);
+/* Dense SPD inverse + log-det on its own (solve(), determinant(): CF:27,133,387). A: in =
+ * SPD matrix (lower triangle read), out = full symmetric inverse. d_logdet, d_info: device. */
+int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream);
+
+/* ---- (4) M-step objective and gradient ---- */
+/* mode 0: logL_GP_mod + gr_GP_mod per individual (CF:181-201, 304-332) with mean = mean[idx],
+ * new_cov = cov[idx, idx]; mode 1: logL_GP + gr_GP (CF:174-179, 279-302: covariance K + C).
+ * f_out[M], g_out[3M] (already negated like the reference: these are the gradients of f),
+ * info_out[M]. active (optional, M bytes): 0 = skip this individual. cov may be NULL (C = 0).
+ * The common-HP objective (CF:203-234, 334-368) is the sum of these over individuals with
+ * theta_stride = 0. */
+int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
+                     const double* y, const int* idx, const double* theta, int theta_stride,
+                     const double* mean, const double* cov, int N, int want_grad,
+                     const unsigned char* active, double* f_out, double* g_out, int* info_out,
+                     void* stream);
+/* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
+ * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
+ * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */
+int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                      const double* mean, const double* m0, const double* cov, int want_grad,
+                      void* work, double* h_out3, int* h_info, void* stream);
+/* Sum of n doubles (deterministic order) -> h_out on the host. Synchronises. */
+int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream);
+
+/* ---- prediction ---- */
+/* pred_gp (MG:172-180) for one new individual with n <= 64 observations and T targets.
+ * mean_obs[n], mean_pred[T]: mean process at the observation / target timestamps; idx_n[n],
+ * idx_t[T]: their positions in cov's grid (cov NULL = plain GP regression, MG:156-160). */
+int magma_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
+                  const int* idx_n, int T, const double* ts, const double* mean_pred,
+                  const int* idx_t, const double* cov, int N, const double* theta3,
+                  double* mean_out, double* var_out, int* d_info, void* stream);
+
+/* ---- dense helpers exposed for tests and for hosts that compose their own pipelines ---- */
+int magma_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,
+                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, void* stream);
+int magma_copy_pad(int N, const double* src, int64_t ld_src, double* dst, int zero_pad,
+                   void* stream);
+int magma_copy_unpad(int N, const double* src, double* dst, int64_t ld_dst, void* stream);
+
+/* ---- batched L-BFGS-B driver (host side, reverse communication) ----
+ * Stands in for `optimr::opm(method = "L-BFGS-B")` -> stats::optim (CF:412-413, 417-418,
+ * 426-429; MG:93-94) with its defaults (lmm 5, factr 1e7, pgtol 0, maxit 100, no bounds),
+ * run in lock-step over B independent problems of dimension d so that one objective launch
+ * serves every problem. ask: fills h_x[B*d] with the points to evaluate and h_active[B];
+ * returns the number of problems still running in *h_nactive. tell: takes f[B], g[B*d] at
+ * those points (inactive entries ignored; non-finite f counts as +inf). */
+typedef struct magma_lbfgsb magma_lbfgsb;
+magma_lbfgsb* magma_lbfgsb_create(int B, int d, const double* h_x0, int m, double factr,
+                                  double pgtol, int maxit);
+int magma_lbfgsb_ask(magma_lbfgsb* s, double* h_x, unsigned char* h_active, int* h_nactive);
+int magma_lbfgsb_tell(magma_lbfgsb* s, const double* h_f, const double* h_g);
+int magma_lbfgsb_result(magma_lbfgsb* s, double* h_x, double* h_f, int* h_iters, int* h_nfev,
+                        int* h_status);
+void magma_lbfgsb_destroy(magma_lbfgsb* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGMA_HIP_H */

@@ -1,0 +1,238 @@
+// C ABI of libmagma_hip.so (see include/magma_hip.h for the contract and reference citations).
+#include "../../include/magma_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace magma {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return 100 + (int)e;
+}
+
+// Carve-up of the caller-provided dense workspace (all offsets in doubles).
+struct Work {
+  double *A0, *T, *inv, *z, *alpha, *tmp, *partials, *scal;
+  int* iinfo;
+  Work(void* base, int Np) {
+    const size_t n2 = (size_t)Np * Np;
+    const int nt = Np / 64;
+    double* p = static_cast<double*>(base);
+    A0 = p; p += n2;
+    T = p; p += n2;
+    inv = p; p += 3 * n2;
+    z = p; p += Np;
+    alpha = p; p += Np;
+    tmp = p; p += Np;
+    partials = p; p += std::max<size_t>(2 * (size_t)nt * nt, 1024);
+    scal = p; p += 16;
+    iinfo = reinterpret_cast<int*>(p);
+  }
+  static size_t bytes(int Np) {
+    const size_t n2 = (size_t)Np * Np;
+    const int nt = Np / 64;
+    return sizeof(double) * (5 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
+  }
+};
+
+static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+static int check_small(int M, int nmax) {
+  if (M < 0) return fail(2, "M must be >= 0");
+  if (nmax < 1 || nmax > MAGMA_NSMALL_MAX)
+    return fail(2, "n_i must be in 1..64 (one wavefront per individual)");
+  return 0;
+}
+
+}  // namespace magma
+
+using namespace magma;
+
+extern "C" {
+
+int magma_hip_version(void) { return 100; }
+
+const char* magma_last_error(void) { return g_err.c_str(); }
+
+int magma_pad(int N) { return ((N + 63) / 64) * 64; }
+
+size_t magma_workspace_bytes(int N) { return Work::bytes(magma_pad(N)); }
+
+int magma_device_count(int* h_count) { return check_hip(hipGetDeviceCount(h_count), "hipGetDeviceCount"); }
+
+int magma_set_device(int device) { return check_hip(hipSetDevice(device), "hipSetDevice"); }
+
+int magma_dev_malloc(void** h_ptr, size_t bytes) { return check_hip(hipMalloc(h_ptr, bytes), "hipMalloc"); }
+
+int magma_dev_free(void* ptr) { return check_hip(hipFree(ptr), "hipFree"); }
+
+int magma_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream) {
+  return check_hip(hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, S(stream)), "memcpy h2d");
+}
+
+int magma_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream) {
+  return check_hip(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, S(stream)), "memcpy d2h");
+}
+
+int magma_memset_zero(void* dst, size_t bytes, void* stream) {
+  return check_hip(hipMemsetAsync(dst, 0, bytes, S(stream)), "memset");
+}
+
+int magma_stream_sync(void* stream) { return check_hip(hipStreamSynchronize(S(stream)), "stream sync"); }
+
+int magma_kern_to_cov_batched(int M, const int64_t* off, const int64_t* off2, const double* t,
+                              const double* theta, int theta_stride, double* K_out, void* stream) {
+  if (M < 0) return fail(2, "M must be >= 0");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  return launch_se_cov_batched(M, off, off2, t, theta, theta_stride, K_out, S(stream));
+}
+
+int magma_kern_to_cov_grid(int N, const double* grid, double theta1, double theta2, double sigma,
+                           double* A, void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  return launch_se_cov_grid(N, magma_pad(N), grid, theta1, theta2, sigma, A, S(stream));
+}
+
+int magma_kern_to_inv_batched(int M, int nmax, const int64_t* off, const int64_t* off2,
+                              const double* t, const double* theta, int theta_stride,
+                              double* Kinv_out, double* logdet_out, int* info_out, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  return launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv_out, logdet_out,
+                               info_out, S(stream));
+}
+
+int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
+                        const int* idx, const double* theta, int theta_stride, int N, double* P,
+                        double* w, int* info_out, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  return launch_estep_scatter(M, nmax, off, t, y, idx, theta, theta_stride, P, magma_pad(N), w,
+                              info_out, S(stream));
+}
+
+int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  const int Np = magma_pad(N);
+  Work wk(work, Np);
+  return launch_spd_inverse(Np, A, d_logdet, d_info, wk.inv, S(stream));
+}
+
+int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                       const double* m0, double* P, double* w, double* mean_out, void* work,
+                       int* h_info, void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  const int Np = magma_pad(N);
+  const size_t n2 = (size_t)Np * Np;
+  hipStream_t st = S(stream);
+  Work wk(work, Np);
+  int rc;
+  if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+  if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  if ((rc = launch_axpy((int64_t)n2, 1.0, wk.A0, P, st))) return rc;
+  if ((rc = launch_symv(Np, wk.A0, m0, wk.tmp, st))) return rc;
+  if ((rc = launch_axpy(Np, 1.0, wk.tmp, w, st))) return rc;
+  if ((rc = launch_spd_inverse(Np, P, wk.scal + 5, wk.iinfo + 1, wk.inv, st))) return rc;
+  if ((rc = launch_symv(Np, P, w, mean_out, st))) return rc;
+  int hinfo[2] = {0, 0};
+  MAGMA_CHECK_HIP(hipMemcpyAsync(hinfo, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  if (h_info) *h_info = hinfo[0] ? hinfo[0] : (hinfo[1] ? -hinfo[1] : 0);
+  return 0;
+}
+
+int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
+                     const double* y, const int* idx, const double* theta, int theta_stride,
+                     const double* mean, const double* cov, int N, int want_grad,
+                     const unsigned char* active, double* f_out, double* g_out, int* info_out,
+                     void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  return launch_indiv_eval(M, nmax, off, t, y, idx, theta, theta_stride, mean, cov, magma_pad(N),
+                           mode, want_grad, active, f_out, g_out, info_out, S(stream));
+}
+
+int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                      const double* mean, const double* m0, const double* cov, int want_grad,
+                      void* work, double* h_out3, int* h_info, void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  const int Np = magma_pad(N);
+  const size_t n2 = (size_t)Np * Np;
+  hipStream_t st = S(stream);
+  Work wk(work, Np);
+  int rc;
+  if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+  if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  // z = mean - m0 on the true grid, zero on the padding
+  MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, mean, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
+  if ((rc = launch_axpy(Np, -1.0, m0, wk.z, st))) return rc;
+  if (Np > N) MAGMA_CHECK_HIP(hipMemsetAsync(wk.z + N, 0, sizeof(double) * (Np - N), st));
+  if ((rc = launch_symv(Np, wk.A0, wk.z, wk.alpha, st))) return rc;
+  if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
+  if ((rc = launch_dot((int64_t)n2, wk.A0, cov, wk.partials, wk.scal + 2, st))) return rc;
+  if (want_grad) {
+    if ((rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st))) return rc;
+    if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2,
+                                     wk.partials, wk.scal + 3, st)))
+      return rc;
+  }
+  if ((rc = launch_theta0_finish(N, Np, wk.scal, wk.scal + 8, want_grad, st))) return rc;
+  int hinfo = 0;
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h_out3, wk.scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipMemcpyAsync(&hinfo, wk.iinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  if (h_info) *h_info = hinfo;
+  return 0;
+}
+
+int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream) {
+  if (n < 0) return fail(2, "n must be >= 0");
+  double* w = static_cast<double*>(work);  // needs >= 1025 doubles
+  hipStream_t st = S(stream);
+  if (int rc = launch_dot(n, x, nullptr, w, w + 1024, st)) return rc;
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h_out, w + 1024, sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int magma_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
+                  const int* idx_n, int T, const double* ts, const double* mean_pred,
+                  const int* idx_t, const double* cov, int N, const double* theta3,
+                  double* mean_out, double* var_out, int* d_info, void* stream) {
+  if (n < 1 || n > MAGMA_NSMALL_MAX) return fail(2, "pred_gp: n must be in 1..64");
+  if (T < 0) return fail(2, "pred_gp: T must be >= 0");
+  if (cov != nullptr && (idx_n == nullptr || idx_t == nullptr))
+    return fail(2, "pred_gp: idx_n / idx_t required with cov");
+  return launch_pred_gp(n, tn, yn, mean_obs, idx_n, T, ts, mean_pred, idx_t, cov,
+                        cov ? magma_pad(N) : 0, theta3, mean_out, var_out, d_info, S(stream));
+}
+
+int magma_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,
+                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc, void* stream) {
+  return launch_gemm_nt(Mr, Nc, K, alpha, A, lda, B, ldb, beta, C, ldc, S(stream));
+}
+
+int magma_copy_pad(int N, const double* src, int64_t ld_src, double* dst, int zero_pad,
+                   void* stream) {
+  return launch_copy_pad(N, magma_pad(N), src, ld_src, dst, zero_pad, S(stream));
+}
+
+int magma_copy_unpad(int N, const double* src, double* dst, int64_t ld_dst, void* stream) {
+  return launch_copy_unpad(N, magma_pad(N), src, dst, ld_dst, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,631 @@
+// Dense union-grid kernels (N x N, FP64): SE covariance on the grid, blocked right-looking
+// Cholesky, triangular inverse by recursive doubling, A^-1 = L^-T L^-1, symmetric products
+// and the theta_0 gradient contraction -- all on v_mfma_f64_16x16x4_f64 tiles.
+//
+// Conventions: every matrix is Np x Np, Np a multiple of 64, column-major with ld = Np; rows
+// and columns >= N are padding that carries the identity (so inverse, log-det and products
+// are unaffected). Tiles are 64 x 64, one 256-thread workgroup (4 wavefronts, 2 x 2, each a
+// 32 x 32 sub-tile = 2 x 2 MFMA blocks). Operands are staged through LDS as S[k][x]
+// (row length 80 doubles: the four 16-lane groups of one MFMA operand read hit disjoint banks).
+//
+// Replaces (Computing_functions.R = CF): kern_to_cov/kern_to_inv vector branch CF:66-81,
+// 121-138; solve(new_inv) CF:387; logL_GP_mod / gr_GP_mod at theta_0 (CF:181-201, 304-332).
+#include "common.h"
+#include "kernels.h"
+
+namespace magma {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int TLD = 80;  // LDS row length (doubles) of a staged 16 x 64 operand slab
+constexpr int NB = 64;
+
+struct TileAcc {
+  v4d c[2][2];  // [ni][mi]
+};
+
+__device__ __forceinline__ void tile_zero(TileAcc& acc) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc.c[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+}
+
+// acc(m, n) += sum_k Aop(m, k) * Bop(n, k), Aop(m,k) = Ap[m + k*lda], Bop(n,k) = Bp[n + k*ldb],
+// m, n in [0,64), k in [0, 16*ksteps). As, Bs: 16*TLD doubles of LDS each.
+// MFMA operand roles are swapped (first operand = B rows) so that the accumulator has m on the
+// fast lane index: lane l, register r holds C(m = wm*32 + mi*16 + (l & 15),
+// n = wn*32 + ni*16 + (l >> 4) + 4 r) -- column-major stores are then 128-byte segments.
+__device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ Ap, int64_t lda,
+                                             const double* __restrict__ Bp, int64_t ldb,
+                                             int ksteps, TileAcc& acc, double* As, double* Bs) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int x4 = (tid & 15) * 4, kr = tid >> 4;
+  const double2* ga = reinterpret_cast<const double2*>(Ap + x4 + (int64_t)kr * lda);
+  const double2* gb = reinterpret_cast<const double2*>(Bp + x4 + (int64_t)kr * ldb);
+  double2 ra0 = ga[0], ra1 = ga[1], rb0 = gb[0], rb1 = gb[1];
+  const int fo = (lane >> 4) * TLD + (lane & 15);
+  for (int s = 0; s < ksteps; ++s) {
+    __syncthreads();
+    *reinterpret_cast<double2*>(&As[kr * TLD + x4]) = ra0;
+    *reinterpret_cast<double2*>(&As[kr * TLD + x4 + 2]) = ra1;
+    *reinterpret_cast<double2*>(&Bs[kr * TLD + x4]) = rb0;
+    *reinterpret_cast<double2*>(&Bs[kr * TLD + x4 + 2]) = rb1;
+    __syncthreads();
+    if (s + 1 < ksteps) {
+      ga = reinterpret_cast<const double2*>(Ap + x4 + (int64_t)(kr + 16 * (s + 1)) * lda);
+      gb = reinterpret_cast<const double2*>(Bp + x4 + (int64_t)(kr + 16 * (s + 1)) * ldb);
+      ra0 = ga[0];
+      ra1 = ga[1];
+      rb0 = gb[0];
+      rb1 = gb[1];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+      const double a0 = As[kk * TLD + fo + wm * 32];
+      const double a1 = As[kk * TLD + fo + wm * 32 + 16];
+      const double b0 = Bs[kk * TLD + fo + wn * 32];
+      const double b1 = Bs[kk * TLD + fo + wn * 32 + 16];
+      acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc.c[0][0], 0, 0, 0);
+      acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc.c[0][1], 0, 0, 0);
+      acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc.c[1][0], 0, 0, 0);
+      acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc.c[1][1], 0, 0, 0);
+    }
+  }
+}
+
+// Visit every accumulator element of this thread: fn(m, n, value&).
+template <class F>
+__device__ __forceinline__ void tile_foreach(TileAcc& acc, F fn) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = wm * 32 + mi * 16 + (lane & 15);
+        const int n = wn * 32 + ni * 16 + (lane >> 4) + 4 * r;
+        fn(m, n, (double)acc.c[ni][mi][r]);
+      }
+}
+
+// ------------------------------------------------------------------ K2: SE covariance on the grid
+__global__ __launch_bounds__(256) void se_cov_grid_kernel(int N, int Np,
+                                                          const double* __restrict__ grid,
+                                                          double th1, double th2, double sigma,
+                                                          double* __restrict__ A) {
+  __shared__ double gr[64], gc[64];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  if (tid < 64) gr[tid] = (r0 + tid < N) ? grid[r0 + tid] : 0.0;
+  else if (tid < 128) gc[tid - 64] = (c0 + tid - 64 < N) ? grid[c0 + tid - 64] : 0.0;
+  __syncthreads();
+  const SEParams p = se_params(th1, th2, sigma);
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    const int gi = r0 + r, gj = c0 + c;
+    double v;
+    if (gi < N && gj < N) {
+      const double d = gr[r] - gc[c];
+      v = (gi == gj) ? (p.eth1 + p.sig2) : exp(p.th1 - p.h * d * d);
+    } else {
+      v = (gi == gj) ? 1.0 : 0.0;
+    }
+    A[(int64_t)gj * Np + gi] = v;
+  }
+}
+
+// ------------------------------------------------------------------ Cholesky panel
+// Step k of the right-looking factorisation. Every workgroup re-factors the 64 x 64 diagonal
+// block A_kk in registers/LDS (cheaper than a launch boundary), then workgroup w > 0 solves
+// L_ik = A_ik L_kk^-T for block row i = k + w, and workgroup 0 stores L_kk and solves the
+// same system against the identity, which yields U_kk = L_kk^-T and X_kk = L_kk^-1 (the
+// leaves of the triangular inverse). Thread (row = tid & 63, ty = tid >> 6) owns the 16
+// elements [row][4q + ty] of a block.
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t ld,
+                                                          int k, double* __restrict__ X,
+                                                          double* __restrict__ U,
+                                                          double* __restrict__ logdet,
+                                                          int* __restrict__ info) {
+  __shared__ double Ls[64 * 65];
+  __shared__ double colbuf[2][64];
+  const int tid = threadIdx.x, row = tid & 63, ty = tid >> 6;
+  const int w = blockIdx.x;
+  double* Akk = A + (int64_t)k * NB * (ld + 1);
+  double d[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[q] = Akk[row + (int64_t)(4 * q + ty) * ld];
+  double pm = 1.0;  // product of pivots as mantissa * 2^pe (pivot = L_jj^2)
+  int pe = 0;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    double* cb = colbuf[j & 1];
+    if (ty == (j & 3)) cb[row] = d[j >> 2];
+    __syncthreads();
+    double djj = cb[j];
+    if (!(djj > 0.0) || !(djj < 1.7e308)) {
+      if (bad == 0) bad = j + 1;
+      djj = 1.0;
+    }
+    {
+      int e;
+      pm *= frexp(djj, &e);
+      pe += e;
+    }
+    const double s = sqrt(djj);
+    const double own = cb[row];
+    if (ty == (j & 3)) Ls[row * 65 + j] = (row > j) ? own / s : ((row == j) ? s : 0.0);
+    const double f = own / djj;
+#pragma unroll
+    for (int q = (j >> 2); q < 16; ++q) {
+      const int c = 4 * q + ty;
+      d[q] = (c > j && c <= row) ? fma(-f, cb[c], d[q]) : d[q];  // select: a branch here crashes hipcc 7.2
+    }
+  }
+  __syncthreads();
+  double b[16];
+  if (w == 0) {
+    if (tid == 0) {
+      logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
+      if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = 4 * q + ty;
+      Akk[row + (int64_t)c * ld] = Ls[row * 65 + c];
+      b[q] = (c == row) ? 1.0 : 0.0;
+    }
+  } else {
+    const double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = Aik[row + (int64_t)(4 * q + ty) * ld];
+  }
+  // X L^T = B, column by column
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    double* cb = colbuf[j & 1];
+    if (ty == (j & 3)) {
+      const double x = b[j >> 2] / Ls[j * 65 + j];
+      b[j >> 2] = x;
+      cb[row] = x;
+    }
+    __syncthreads();
+    const double x = cb[row];
+#pragma unroll
+    for (int q = (j >> 2); q < 16; ++q) {
+      const int c = 4 * q + ty;
+      b[q] = (c > j) ? fma(-x, Ls[c * 65 + j], b[q]) : b[q];
+    }
+  }
+  if (w == 0) {
+    double* Ukk = U + (int64_t)k * NB * (ld + 1);
+    double* Xkk = X + (int64_t)k * NB * (ld + 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = 4 * q + ty;
+      Ukk[row + (int64_t)c * ld] = b[q];
+      Xkk[c + (int64_t)row * ld] = b[q];
+    }
+  } else {
+    double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Aik[row + (int64_t)(4 * q + ty) * ld] = b[q];
+  }
+}
+
+// ------------------------------------------------------------------ trailing update
+// A_ij -= L_ik L_jk^T for k < j <= i.
+__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A, int64_t ld,
+                                                          int k) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  if (bj > bi) return;
+  const int i = k + 1 + bi, j = k + 1 + bj;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(A + (int64_t)i * NB + (int64_t)k * NB * ld, ld,
+               A + (int64_t)j * NB + (int64_t)k * NB * ld, ld, 4, acc, As, Bs);
+  double* C = A + (int64_t)i * NB + (int64_t)j * NB * ld;
+  tile_foreach(acc, [&](int m, int n, double v) { C[m + (int64_t)n * ld] -= v; });
+}
+
+// ------------------------------------------------------------------ triangular inverse
+// Node p at `depth` of the balanced binary tree over block indices [0, nt).
+__device__ __forceinline__ void node_range(int nt, int depth, int p, int& lo, int& mid,
+                                           int& hi) {
+  lo = 0;
+  hi = nt;
+  for (int b = depth - 1; b >= 0; --b) {
+    const int m = (lo + hi) >> 1;
+    if ((p >> b) & 1) lo = m; else hi = m;
+  }
+  mid = (lo + hi) >> 1;
+}
+
+// Step A: W[b1, b2] = U11 L21^T  (U upper triangular: k-tiles start at the m-tile).
+__global__ __launch_bounds__(256) void trtri_a_kernel(const double* __restrict__ L,
+                                                      const double* __restrict__ U,
+                                                      double* __restrict__ W, int64_t ld,
+                                                      int nt, int depth) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  int lo, mid, hi;
+  node_range(nt, depth, blockIdx.z, lo, mid, hi);
+  if (hi - lo < 2) return;
+  const int mt = lo + blockIdx.x, ntile = mid + blockIdx.y;
+  if (mt >= mid || ntile >= hi) return;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(U + (int64_t)mt * NB + (int64_t)mt * NB * ld, ld,
+               L + (int64_t)ntile * NB + (int64_t)mt * NB * ld, ld, (mid - mt) * 4, acc, As, Bs);
+  double* C = W + (int64_t)mt * NB + (int64_t)ntile * NB * ld;
+  tile_foreach(acc, [&](int m, int n, double v) { C[m + (int64_t)n * ld] = v; });
+}
+
+// Step B: U12 = -W U22 = -W X22^T (X lower triangular: k-tiles end at the n-tile); X21 = U12^T.
+__global__ __launch_bounds__(256) void trtri_b_kernel(const double* __restrict__ W,
+                                                      double* __restrict__ X,
+                                                      double* __restrict__ U, int64_t ld, int nt,
+                                                      int depth) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  int lo, mid, hi;
+  node_range(nt, depth, blockIdx.z, lo, mid, hi);
+  if (hi - lo < 2) return;
+  const int mt = lo + blockIdx.x, ntile = mid + blockIdx.y;
+  if (mt >= mid || ntile >= hi) return;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(W + (int64_t)mt * NB + (int64_t)mid * NB * ld, ld,
+               X + (int64_t)ntile * NB + (int64_t)mid * NB * ld, ld, (ntile - mid + 1) * 4, acc,
+               As, Bs);
+  double* Cu = U + (int64_t)mt * NB + (int64_t)ntile * NB * ld;
+  double* Cx = X + (int64_t)ntile * NB + (int64_t)mt * NB * ld;
+  tile_foreach(acc, [&](int m, int n, double v) {
+    Cu[m + (int64_t)n * ld] = -v;
+    Cx[n + (int64_t)m * ld] = -v;
+  });
+}
+
+// A^-1 = U U^T: tile (i >= j) = sum_{k >= i} U(i-block, k) U(j-block, k)^T, mirrored.
+__global__ __launch_bounds__(256) void lauum_kernel(const double* __restrict__ U,
+                                                    double* __restrict__ Ainv, int64_t ld,
+                                                    int nt) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  const int i = blockIdx.x, j = blockIdx.y;
+  if (j > i) return;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(U + (int64_t)i * NB + (int64_t)i * NB * ld, ld,
+               U + (int64_t)j * NB + (int64_t)i * NB * ld, ld, (nt - i) * 4, acc, As, Bs);
+  double* C = Ainv + (int64_t)i * NB + (int64_t)j * NB * ld;
+  double* Ct = Ainv + (int64_t)j * NB + (int64_t)i * NB * ld;
+  const bool diag = (i == j);
+  tile_foreach(acc, [&](int m, int n, double v) {
+    C[m + (int64_t)n * ld] = v;
+    if (!diag) Ct[n + (int64_t)m * ld] = v;
+  });
+}
+
+// ------------------------------------------------------------------ general C = alpha A B^T + beta C
+__global__ __launch_bounds__(256) void gemm_nt_kernel(int K, double alpha,
+                                                      const double* __restrict__ A, int64_t lda,
+                                                      const double* __restrict__ B, int64_t ldb,
+                                                      double beta, double* __restrict__ C,
+                                                      int64_t ldc) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(A + (int64_t)blockIdx.x * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc,
+               As, Bs);
+  double* Ct = C + (int64_t)blockIdx.x * NB + (int64_t)blockIdx.y * NB * ldc;
+  if (beta == 0.0) {
+    tile_foreach(acc, [&](int m, int n, double v) { Ct[m + (int64_t)n * ldc] = alpha * v; });
+  } else {
+    tile_foreach(acc, [&](int m, int n, double v) {
+      double* p = &Ct[m + (int64_t)n * ldc];
+      *p = alpha * v + beta * *p;
+    });
+  }
+}
+
+// ------------------------------------------------------------------ theta_0 gradient contraction
+// Z = T Kinv (never stored), W = alpha alpha' + Z - Kinv, partial sums over the true N x N
+// region of sum(W o K_nl) and sum(W o dK/dtheta2); lower tiles only (off-diagonal tiles x2).
+__global__ __launch_bounds__(256) void theta0_contract_kernel(
+    int N, int Np, const double* __restrict__ T, const double* __restrict__ Kinv,
+    const double* __restrict__ alpha, const double* __restrict__ grid, double th1, double th2,
+    double* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  __shared__ double red[2][4];
+  const int i = blockIdx.x, j = blockIdx.y, nt = gridDim.x;
+  double* out = partials + 2 * ((int64_t)j * nt + i);
+  if (j > i) {
+    if (threadIdx.x == 0) {
+      out[0] = 0.0;
+      out[1] = 0.0;
+    }
+    return;
+  }
+  const int64_t ld = Np;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(T + (int64_t)i * NB, ld, Kinv + (int64_t)j * NB, ld, Np / 16, acc, As, Bs);
+  const double h = 0.5 * exp(-th2);
+  const double eth1 = exp(th1);
+  double s1 = 0.0, s2 = 0.0;
+  tile_foreach(acc, [&](int m, int n, double v) {
+    const int gm = i * NB + m, gn = j * NB + n;
+    if (gm < N && gn < N) {
+      const double W = v + alpha[gm] * alpha[gn] - Kinv[gm + (int64_t)gn * ld];
+      const double d = grid[gm] - grid[gn];
+      const double gq = h * d * d;
+      const double knl = (gm == gn) ? eth1 : exp(th1 - gq);
+      s1 += W * knl;
+      s2 += W * knl * gq;
+    }
+  });
+  const double wgt = (i == j) ? 1.0 : 2.0;
+  s1 = wave_sum(s1) * wgt;
+  s2 = wave_sum(s2) * wgt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s1;
+    red[1][wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_pairs_kernel(int64_t n, const double* __restrict__ p,
+                                                           double* __restrict__ out2) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t e = threadIdx.x; e < n; e += 256) {
+    s1 += p[2 * e];
+    s2 += p[2 * e + 1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s1;
+    red[1][wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    out2[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// ------------------------------------------------------------------ BLAS-1/2 helpers
+// y_j = sum_i A[i + j*ld] x_i  (A symmetric: column j == row j). One wavefront per column.
+__global__ __launch_bounds__(256) void symv_kernel(int Np, const double* __restrict__ A,
+                                                   const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= Np) return;
+  const double* col = A + (int64_t)j * Np;
+  double s = 0.0;
+  for (int i = lane; i < Np; i += 64) s = fma(col[i], x[i], s);
+  s = wave_sum(s);
+  if (lane == 0) y[j] = s;
+}
+
+__global__ void axpy_kernel(int64_t n, double alpha, const double* __restrict__ x,
+                            double* __restrict__ y) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    y[e] = fma(alpha, x[e], y[e]);
+}
+
+__global__ void fill_kernel(int64_t n, double v, double* __restrict__ x) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    x[e] = v;
+}
+
+// out[0] = sum_e a[e] b[e] over n elements (deterministic two-stage: per-block partials in
+// `scratch`, then one block). Used for z'alpha (vectors) and sum(Kinv o C) (N x N region).
+__global__ __launch_bounds__(256) void dot_stage1_kernel(int64_t n, const double* __restrict__ a,
+                                                         const double* __restrict__ b,
+                                                         double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  if (b != nullptr) {
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+      s = fma(a[e], b[e], s);
+  } else {  // plain sum
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+      s += a[e];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sum_stage2_kernel(int n, const double* __restrict__ partial,
+                                                         double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int e = threadIdx.x; e < n; e += 256) s += partial[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dst (Np x Np, ld Np) <- src (N x N, ld lds); padding: identity (zero_pad = 0) or zeros.
+__global__ void copy_pad_kernel(int N, int Np, const double* __restrict__ src, int64_t lds,
+                                double* __restrict__ dst, int zero_pad) {
+  const int64_t total = (int64_t)Np * Np;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % Np), c = (int)(e / Np);
+    double v;
+    if (r < N && c < N) v = src[r + (int64_t)c * lds];
+    else v = (r == c && !zero_pad) ? 1.0 : 0.0;
+    dst[e] = v;
+  }
+}
+
+__global__ void copy_unpad_kernel(int N, int Np, const double* __restrict__ src,
+                                  double* __restrict__ dst, int64_t ldd) {
+  const int64_t total = (int64_t)N * N;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % N), c = (int)(e / N);
+    dst[r + (int64_t)c * ldd] = src[r + (int64_t)c * Np];
+  }
+}
+
+// Rows/cols >= N of an Np x Np matrix <- identity (after a scatter into a zeroed buffer).
+__global__ void set_identity_pad_kernel(int N, int Np, double* __restrict__ A) {
+  for (int r = N + blockIdx.x * blockDim.x + threadIdx.x; r < Np; r += gridDim.x * blockDim.x)
+    A[(int64_t)r * Np + r] = 1.0;
+}
+
+// scal: [0] logdet, [1] ssq, [2] cor, [3] s1, [4] s2  ->  out3 = (f, g1, g2)
+__global__ void theta0_finish_kernel(int N, int Np, const double* __restrict__ scal,
+                                     double* __restrict__ out3, int want_grad) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // scal[2] was summed over the padded Np x Np arrays: each pad diagonal entry adds 1 * 1
+    out3[0] = 0.5 * ((double)N * 1.8378770664093454835606594728112 + scal[0] + scal[1]) +
+              0.5 * (scal[2] - (double)(Np - N));
+    out3[1] = want_grad ? -0.5 * scal[3] : 0.0;
+    out3[2] = want_grad ? -0.5 * scal[4] : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2, double sigma,
+                       double* A, hipStream_t st) {
+  dim3 g(Np / 64, Np / 64);
+  hipLaunchKernelGGL(se_cov_grid_kernel, g, dim3(256), 0, st, N, Np, grid, th1, th2, sigma, A);
+  return check_hip(hipGetLastError(), "se_cov_grid");
+}
+
+size_t spd_inverse_workspace_doubles(int Np) { return 3 * (size_t)Np * Np; }
+
+int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* work,
+                       hipStream_t st) {
+  const int nt = Np / NB;
+  const int64_t ld = Np;
+  double* X = work;
+  double* U = work + (size_t)Np * Np;
+  double* W = work + 2 * (size_t)Np * Np;
+  MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+  for (int k = 0; k < nt; ++k) {
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3(nt - k), dim3(256), 0, st, A, ld, k, X, U, logdet,
+                       info);
+    if (k + 1 < nt) {
+      const int rem = nt - k - 1;
+      hipLaunchKernelGGL(syrk_update_kernel, dim3(rem, rem), dim3(256), 0, st, A, ld, k);
+    }
+  }
+  int depth = 0;
+  while ((1 << depth) < nt) ++depth;
+  for (int d = depth - 1; d >= 0; --d) {
+    const int nodes = 1 << d;
+    const int maxsz = (nt + nodes - 1) / nodes + 1;  // upper bound on a node's block count
+    const int half = (maxsz + 1) / 2;
+    dim3 g(half, half, nodes);
+    hipLaunchKernelGGL(trtri_a_kernel, g, dim3(256), 0, st, A, U, W, ld, nt, d);
+    hipLaunchKernelGGL(trtri_b_kernel, g, dim3(256), 0, st, W, X, U, ld, nt, d);
+  }
+  hipLaunchKernelGGL(lauum_kernel, dim3(nt, nt), dim3(256), 0, st, U, A, ld, nt);
+  return check_hip(hipGetLastError(), "spd_inverse");
+}
+
+int launch_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                   hipStream_t st) {
+  if (Mr % 64 || Nc % 64 || K % 16) return fail(2, "gemm_nt: dimensions must be padded (64/64/16)");
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(Mr / 64, Nc / 64), dim3(256), 0, st, K, alpha, A, lda, B,
+                     ldb, beta, C, ldc);
+  return check_hip(hipGetLastError(), "gemm_nt");
+}
+
+int launch_symv(int Np, const double* A, const double* x, double* yout, hipStream_t st) {
+  hipLaunchKernelGGL(symv_kernel, dim3((Np + 3) / 4), dim3(256), 0, st, Np, A, x, yout);
+  return check_hip(hipGetLastError(), "symv");
+}
+
+static int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_axpy(int64_t n, double alpha, const double* x, double* yio, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, alpha, x, yio);
+  return check_hip(hipGetLastError(), "axpy");
+}
+
+int launch_fill(int64_t n, double v, double* x, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, v, x);
+  return check_hip(hipGetLastError(), "fill");
+}
+
+// partial: >= 1024 doubles of scratch
+int launch_dot(int64_t n, const double* a, const double* b, double* partial, double* out,
+               hipStream_t st) {
+  int g = grid_for(n);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(dot_stage1_kernel, dim3(g), dim3(256), 0, st, n, a, b, partial);
+  hipLaunchKernelGGL(sum_stage2_kernel, dim3(1), dim3(256), 0, st, g, partial, out);
+  return check_hip(hipGetLastError(), "dot");
+}
+
+int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
+                           const double* alpha, const double* grid, double th1, double th2,
+                           double* partials, double* out2, hipStream_t st) {
+  const int nt = Np / NB;
+  hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, T, Kinv, alpha,
+                     grid, th1, th2, partials);
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
+                     out2);
+  return check_hip(hipGetLastError(), "theta0_contract");
+}
+
+int launch_set_identity_pad(int N, int Np, double* A, hipStream_t st) {
+  if (Np > N) hipLaunchKernelGGL(set_identity_pad_kernel, dim3(1), dim3(64), 0, st, N, Np, A);
+  return check_hip(hipGetLastError(), "set_identity_pad");
+}
+
+int launch_copy_pad(int N, int Np, const double* src, int64_t lds, double* dst, int zero_pad,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(copy_pad_kernel, dim3(grid_for((int64_t)Np * Np)), dim3(256), 0, st, N, Np,
+                     src, lds, dst, zero_pad);
+  return check_hip(hipGetLastError(), "copy_pad");
+}
+
+int launch_copy_unpad(int N, int Np, const double* src, double* dst, int64_t ldd,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(copy_unpad_kernel, dim3(grid_for((int64_t)N * N)), dim3(256), 0, st, N, Np,
+                     src, dst, ldd);
+  return check_hip(hipGetLastError(), "copy_unpad");
+}
+
+int launch_theta0_finish(int N, int Np, const double* scal, double* out3, int want_grad,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(theta0_finish_kernel, dim3(1), dim3(64), 0, st, N, Np, scal, out3,
+                     want_grad);
+  return check_hip(hipGetLastError(), "theta0_finish");
+}
+
+}  // namespace magma

@@ -1,0 +1,53 @@
+// Internal launcher prototypes (device pointers, explicit stream). See small.hip / dense.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace magma {
+
+// ---- per-individual (one wavefront per matrix) ----
+int launch_se_cov_batched(int M, const int64_t* off, const int64_t* off2, const double* t,
+                          const double* theta, int tstride, double* out, hipStream_t st);
+int launch_se_inv_batched(int M, int nmax, const int64_t* off, const int64_t* off2,
+                          const double* t, const double* theta, int tstride, double* out,
+                          double* logdet, int* info, hipStream_t st);
+int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
+                         const int* idx, const double* theta, int tstride, double* P,
+                         int64_t ldp, double* w, int* info, hipStream_t st);
+int launch_indiv_eval(int M, int nmax, const int64_t* off, const double* t, const double* y,
+                      const int* idx, const double* theta, int tstride, const double* mean,
+                      const double* cov, int64_t ldc, int mode, int want_grad,
+                      const unsigned char* active, double* f, double* g, int* info,
+                      hipStream_t st);
+int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
+                   const int* idx_n, int T, const double* ts, const double* mean_pred,
+                   const int* idx_t, const double* cov, int64_t ldc, const double* theta,
+                   double* out_mean, double* out_var, int* info, hipStream_t st);
+
+// ---- dense union-grid (N x N, padded to a multiple of 64, column-major, ld = Np) ----
+int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2, double sigma,
+                       double* A, hipStream_t st);
+size_t spd_inverse_workspace_doubles(int Np);
+// A: in = SPD (lower triangle read), out = full symmetric inverse. logdet/info: device scalars.
+int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* work,
+                       hipStream_t st);
+int launch_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                   hipStream_t st);
+int launch_symv(int Np, const double* A, const double* x, double* yout, hipStream_t st);
+int launch_axpy(int64_t n, double alpha, const double* x, double* yio, hipStream_t st);
+int launch_dot(int64_t n, const double* a, const double* b, double* partial, double* out,
+               hipStream_t st);
+int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
+                           const double* alpha, const double* grid, double th1, double th2,
+                           double* partials, double* out2, hipStream_t st);
+int launch_fill(int64_t n, double v, double* x, hipStream_t st);
+int launch_set_identity_pad(int N, int Np, double* A, hipStream_t st);
+int launch_copy_pad(int N, int Np, const double* src, int64_t lds, double* dst, int zero_pad,
+                    hipStream_t st);
+int launch_copy_unpad(int N, int Np, const double* src, double* dst, int64_t ldd,
+                      hipStream_t st);
+int launch_theta0_finish(int N, int Np, const double* scal, double* out3, int want_grad,
+                         hipStream_t st);
+
+}  // namespace magma
