@@ -1,0 +1,16 @@
+"""magma_amd: MI355X-native (gfx950, FP64) implementation of MAGMA's multi-task-GP EM hot path.
+
+The public surface mirrors the reference's R functions (MAGMA.R / Computing_functions.R);
+everything numeric runs in libmagma_hip.so (hand-written HIP kernels behind a C ABI).
+"""
+from .api import (kernel, kernel_mu, mat_dist, kern_to_cov, kern_to_inv, logL_GP, gr_GP,
+                  logL_GP_mod, gr_GP_mod, logL_GP_mod_common_hp, gr_GP_mod_common_hp,
+                  logL_monitoring, e_step, m_step, training, train_new_gp, posterior_mu, pred_gp,
+                  full_algo)
+from .engine import Dataset, Engine, HipBackend, Comm
+from .lbfgsb import minimize_batch
+
+__all__ = ["kernel", "kernel_mu", "mat_dist", "kern_to_cov", "kern_to_inv", "logL_GP", "gr_GP",
+           "logL_GP_mod", "gr_GP_mod", "logL_GP_mod_common_hp", "gr_GP_mod_common_hp",
+           "logL_monitoring", "e_step", "m_step", "training", "train_new_gp", "posterior_mu",
+           "pred_gp", "full_algo", "Dataset", "Engine", "HipBackend", "Comm", "minimize_batch"]

@@ -1,0 +1,394 @@
+"""Device engine behind the R-named API of `magma_amd.api`.
+
+`Dataset`    host-side ragged layout of a db (replaces the reference's per-call
+             `filter(ID == i)` scans and `paste0('X', t)` name matching with offsets and an
+             int32 union-grid index).
+`HipBackend` this rank's shard resident in HBM (torch tensors are only the allocator) and
+             thin wrappers over the C ABI of libmagma_hip.so.
+`Engine`     the EM logic of MAGMA.R:15-82 / Computing_functions.R:371-437 on top of a backend,
+             including the multi-rank reductions (torch.distributed: RCCL on GPUs, gloo in the
+             CPU tests, where a test-only backend stands in for HipBackend).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from .lbfgsb import minimize_batch
+
+N_SMALL_MAX = 64
+
+
+def unique_in_order(a):
+    _, first = np.unique(a, return_index=True)
+    return np.asarray(a)[np.sort(first)]
+
+
+class Dataset:
+    """Ragged individuals + sorted union grid. Each individual's (t, y) are sorted jointly by
+    timestamp: the reference sorts timestamps inside kern_to_cov/kern_to_inv (CF:74,95,129,151)
+    but takes outputs in db order, so it is only self-consistent for sorted input."""
+
+    def __init__(self, db, extra_timestamps=None):
+        ids_col = np.asarray(db["ID"])
+        t_col = np.asarray(db["Timestamp"], dtype=np.float64)
+        y_col = np.asarray(db["Output"], dtype=np.float64)
+        self.ids = list(unique_in_order(ids_col)) if ids_col.size else []
+        ts, ys, off = [], [], [0]
+        for i in self.ids:
+            sel = np.nonzero(ids_col == i)[0]
+            order = np.argsort(t_col[sel], kind="stable")
+            ts.append(t_col[sel][order])
+            ys.append(y_col[sel][order])
+            off.append(off[-1] + sel.size)
+        self.M = len(self.ids)
+        self.off = np.asarray(off, dtype=np.int64)
+        self.t = np.concatenate(ts) if ts else np.zeros(0)
+        self.y = np.concatenate(ys) if ys else np.zeros(0)
+        pieces = [self.t]
+        if extra_timestamps is not None:
+            pieces.append(np.asarray(extra_timestamps, dtype=np.float64).ravel())
+        self.grid = np.unique(np.concatenate(pieces))
+        self.N = int(self.grid.size)
+        self.idx = np.searchsorted(self.grid, self.t).astype(np.int32)
+        n = np.diff(self.off)
+        self.nmax = int(n.max()) if n.size else 1
+        if self.nmax > N_SMALL_MAX:
+            raise ValueError(f"an individual has {self.nmax} observations; the HIP path handles "
+                             f"n_i <= {N_SMALL_MAX} (one wavefront per individual)")
+        for i in range(self.M):
+            ti = self.t[self.off[i]:self.off[i + 1]]
+            if np.any(np.diff(ti) <= 0):
+                raise ValueError(f"individual {self.ids[i]!r} has duplicated timestamps")
+
+    @classmethod
+    def from_arrays(cls, off, t, y, grid=None, ids=None):
+        """Build directly from ragged arrays (timestamps ascending per individual)."""
+        self = cls.__new__(cls)
+        self.off = np.asarray(off, dtype=np.int64)
+        self.M = self.off.size - 1
+        self.ids = list(range(self.M)) if ids is None else list(ids)
+        self.t = np.ascontiguousarray(t, dtype=np.float64)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self.grid = np.unique(self.t) if grid is None else np.asarray(grid, dtype=np.float64)
+        self.N = int(self.grid.size)
+        self.idx = np.searchsorted(self.grid, self.t).astype(np.int32)
+        self.nmax = int(np.diff(self.off).max()) if self.M else 1
+        if self.nmax > N_SMALL_MAX:
+            raise ValueError("n_i <= 64 required")
+        return self
+
+    def shard(self, rank, world):
+        """Contiguous block of individuals for `rank` (equal counts: n_i is near-constant in
+        the target workloads). Returns (lo, hi)."""
+        per = (self.M + world - 1) // world
+        lo = min(self.M, rank * per)
+        return lo, min(self.M, lo + per)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HipBackend:
+    """One rank's shard of the dataset in HBM + the dense workspace, calling libmagma_hip.so."""
+
+    def __init__(self, ds, lo, hi, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.MagmaHipError("no GPU visible: the HIP path has no CPU fallback")
+        self.lib = _lib.load()
+        self.dev = torch.device(device if device is not None else "cuda")
+        self.N = ds.N
+        self.Np = int(self.lib.magma_pad(ds.N))
+        self.M = hi - lo
+        self.nmax = ds.nmax
+        f64, dev = torch.float64, self.dev
+        o0, o1 = int(ds.off[lo]), int(ds.off[hi])
+        self.n_i = np.diff(ds.off[lo:hi + 1])
+        self.off = torch.from_numpy(ds.off[lo:hi + 1] - o0).to(dev)
+        self.t = torch.from_numpy(ds.t[o0:o1].copy()).to(dev)
+        self.y = torch.from_numpy(ds.y[o0:o1].copy()).to(dev)
+        self.idx = torch.from_numpy(ds.idx[o0:o1].copy()).to(dev)
+        gridp = np.zeros(self.Np)
+        gridp[:ds.N] = ds.grid
+        self.grid = torch.from_numpy(gridp).to(dev)
+        Mb = max(self.M, 1)
+        self.theta = torch.zeros(Mb * 3, dtype=f64, device=dev)
+        self.f = torch.zeros(Mb, dtype=f64, device=dev)
+        self.g = torch.zeros(Mb * 3, dtype=f64, device=dev)
+        self.info = torch.zeros(Mb, dtype=torch.int32, device=dev)
+        self.active = torch.ones(Mb, dtype=torch.uint8, device=dev)
+        self.P = torch.zeros(self.Np * self.Np, dtype=f64, device=dev)  # precision, then cov
+        self.w = torch.zeros(self.Np, dtype=f64, device=dev)
+        self.mean = torch.zeros(self.Np, dtype=f64, device=dev)
+        self.m0 = torch.zeros(self.Np, dtype=f64, device=dev)
+        wbytes = int(self.lib.magma_workspace_bytes(ds.N))
+        self.work = torch.empty((wbytes + 7) // 8, dtype=f64, device=dev)
+        self.cov = self.P  # alias: after estep_finish P holds the covariance
+
+    # -- plumbing
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def sync(self):
+        self.torch.cuda.current_stream(self.dev).synchronize()
+
+    def _set_theta(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.ndim == 1:  # common hyper-parameters: one triple, stride 0
+            self.theta[:3].copy_(self.torch.from_numpy(th))
+            return 0
+        assert th.shape == (self.M, 3), th.shape
+        self.theta[:3 * self.M].copy_(self.torch.from_numpy(th.reshape(-1)))
+        return 3
+
+    def set_m0(self, m0):
+        v = np.zeros(self.Np)
+        m0 = np.asarray(m0, dtype=np.float64).ravel()
+        v[:self.N] = m0[0] if m0.size == 1 else m0
+        self.m0.copy_(self.torch.from_numpy(v))
+
+    def set_mean_cov(self, mean, cov):
+        """Load a hyper-posterior (host arrays on this engine's grid) into device buffers."""
+        v = np.zeros(self.Np)
+        v[:self.N] = mean
+        self.mean.copy_(self.torch.from_numpy(v))
+        c = np.eye(self.Np)
+        c[:self.N, :self.N] = cov
+        self.P.copy_(self.torch.from_numpy(c.T.reshape(-1).copy()))
+
+    # -- E-step
+    def estep_scatter(self, theta):
+        """Zero P, w and scatter this shard's K_i^-1 / K_i^-1 y_i. Returns (P, w) tensors for
+        the caller to all-reduce, and the number of flagged (non-SPD) individuals."""
+        stride = self._set_theta(theta)
+        self.P.zero_()
+        self.w.zero_()
+        if self.M > 0:
+            _lib.call("magma_estep_scatter", self.M, self.nmax, _ptr(self.off), _ptr(self.t),
+                      _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, self.N,
+                      _ptr(self.P), _ptr(self.w), _ptr(self.info), self.stream())
+        return self.P, self.w
+
+    def n_flagged(self):
+        if self.M == 0:
+            return 0
+        return int((self.info[:self.M] != 0).sum().item())
+
+    def estep_finish(self, theta0, pen_diag):
+        info = C.c_int(0)
+        _lib.call("magma_estep_finish", self.N, _ptr(self.grid), float(theta0[0]),
+                  float(theta0[1]), float(pen_diag), _ptr(self.m0), _ptr(self.P), _ptr(self.w),
+                  _ptr(self.mean), _ptr(self.work), C.byref(info), self.stream())
+        return info.value
+
+    # -- M-step objective / gradient
+    def indiv_eval(self, theta, want_grad=True, mode=0, active=None, use_cov=True):
+        """Per-individual f (and gradient) at `theta` ([M,3] or common [3]) against the device
+        resident mean/cov. Returns host arrays f[M], g[M,3] (g None without want_grad)."""
+        if self.M == 0:
+            return np.zeros(0), (np.zeros((0, 3)) if want_grad else None)
+        stride = self._set_theta(theta)
+        act = None
+        if active is not None:
+            self.active[:self.M].copy_(self.torch.from_numpy(
+                np.ascontiguousarray(active, dtype=np.uint8)))
+            act = self.active
+        _lib.call("magma_indiv_eval", int(mode), self.M, self.nmax, _ptr(self.off), _ptr(self.t),
+                  _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, _ptr(self.mean),
+                  _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(act),
+                  _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
+        f = self.f[:self.M].cpu().numpy()
+        g = self.g[:3 * self.M].cpu().numpy().reshape(self.M, 3) if want_grad else None
+        return f, g
+
+    def theta0_eval(self, theta0, pen_diag, want_grad=True):
+        out = (C.c_double * 3)()
+        info = C.c_int(0)
+        _lib.call("magma_theta0_eval", self.N, _ptr(self.grid), float(theta0[0]),
+                  float(theta0[1]), float(pen_diag), _ptr(self.mean), _ptr(self.m0),
+                  _ptr(self.cov), int(bool(want_grad)), _ptr(self.work), out, C.byref(info),
+                  self.stream())
+        f = out[0] if info.value == 0 else float("nan")
+        return f, np.array([out[1], out[2]]), info.value
+
+    # -- results back to the host
+    def get_mean(self):
+        return self.mean[:self.N].cpu().numpy()
+
+    def get_cov(self):
+        c = self.P.view(self.Np, self.Np)[:self.N, :self.N]
+        return c.t().contiguous().cpu().numpy()  # column-major -> numpy [row, col]
+
+    def get_cov_diag(self):
+        return self.P.view(self.Np, self.Np).diagonal()[:self.N].cpu().numpy()
+
+
+class Comm:
+    """torch.distributed plumbing; `None` group = single process."""
+
+    def __init__(self, dist=None):
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+
+    def allreduce_(self, tensor):
+        if self.world > 1:
+            self.dist.all_reduce(tensor)
+        return tensor
+
+    def allreduce_host(self, arr, like=None):
+        """Sum a small host array over ranks (through a tensor on the backend's device)."""
+        if self.world == 1:
+            return arr
+        import torch
+        dev = like.device if like is not None else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def bcast_host(self, arr, like=None, src=0):
+        if self.world == 1:
+            return arr
+        import torch
+        dev = like.device if like is not None else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
+        self.dist.broadcast(t, src)
+        return t.cpu().numpy()
+
+    def allgather_rows(self, local, counts, like=None):
+        """Concatenate per-rank [m_r, k] arrays in rank order (m_r = counts[r])."""
+        if self.world == 1:
+            return local
+        import torch
+        dev = like.device if like is not None else "cpu"
+        k = local.shape[1]
+        mx = max(counts)
+        buf = np.zeros((mx, k))
+        buf[:local.shape[0]] = local
+        t = torch.from_numpy(buf).to(dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)], axis=0)
+
+
+class Engine:
+    """EM logic on a backend. All hyper-parameter arrays are host NumPy; theta_i is the global
+    [M, 3] array replicated on every rank, each rank evaluates rows lo:hi."""
+
+    def __init__(self, ds, backend_factory=None, comm=None, device=None):
+        self.ds = ds
+        self.comm = comm or Comm(None)
+        self.lo, self.hi = ds.shard(self.comm.rank, self.comm.world)
+        self.counts = [ds.shard(r, self.comm.world)[1] - ds.shard(r, self.comm.world)[0]
+                       for r in range(self.comm.world)]
+        factory = backend_factory or (lambda d, lo, hi: HipBackend(d, lo, hi, device))
+        self.be = factory(ds, self.lo, self.hi)
+        self.stats = {"theta0_evals": 0, "indiv_rounds": 0, "common_evals": 0, "flagged": 0}
+
+    # ------------------------------------------------------------ E-step (CF:371-395)
+    def e_step(self, theta0, theta_i, pen_diag, m0):
+        be = self.be
+        be.set_m0(m0)
+        common = np.ndim(theta_i) == 1
+        P, w = be.estep_scatter(theta_i if common else theta_i[self.lo:self.hi])
+        self.comm.allreduce_(P)
+        self.comm.allreduce_(w)
+        self.stats["flagged"] += be.n_flagged()
+        info = be.estep_finish(theta0, pen_diag)
+        return info
+
+    # ------------------------------------------------------------ objectives
+    def f0(self, theta0, pen_diag, want_grad=True):
+        self.stats["theta0_evals"] += 1
+        f, g, _ = self.be.theta0_eval(theta0, pen_diag, want_grad)
+        return f, g
+
+    def sum_fi(self, theta_i, want_grad=False):
+        """Sum over ALL individuals of logL_GP_mod (and gradient sum): the common-HP objective
+        (CF:203-234, 334-368) or the individual part of logL_monitoring (CF:254-261)."""
+        common = np.ndim(theta_i) == 1
+        f, g = self.be.indiv_eval(theta_i if common else theta_i[self.lo:self.hi], want_grad)
+        loc = np.zeros(4)
+        loc[0] = f.sum()
+        if want_grad:
+            loc[1:] = g.sum(axis=0)
+        tot = self.comm.allreduce_host(loc, like=getattr(self.be, "w", None))
+        return tot[0], tot[1:]
+
+    def logL_monitoring(self, theta0, theta_i):
+        """CF:236-264."""
+        sig = theta_i[2] if np.ndim(theta_i) == 1 else theta_i[:, 2].mean()
+        ll_0, _ = self.f0(theta0, sig, want_grad=False)
+        s, _ = self.sum_fi(theta_i, want_grad=False)
+        return -ll_0 - s
+
+    # ------------------------------------------------------------ M-step (CF:397-437)
+    def m_step(self, theta0, theta_i, common_hp, opt_kw=None):
+        kw = dict(m=5, factr=1e7, pgtol=0.0, maxit=100)
+        kw.update(opt_kw or {})
+        like = getattr(self.be, "w", None)
+        pen_diag = float(np.mean(2.0 * theta_i[:, 2]))  # CF:409
+
+        def ev0(x, act):
+            f, g = self.f0(x[0], pen_diag, True)
+            return np.array([f]), g[None, :]
+        r0 = minimize_batch(np.asarray(theta0, dtype=np.float64)[None, :], ev0, **kw)
+        new_theta0 = self.comm.bcast_host(r0["x"][0], like=like)
+
+        if common_hp:
+            def evc(x, act):
+                self.stats["common_evals"] += 1
+                f, g = self.sum_fi(x[0], True)
+                return np.array([f]), g[None, :]
+            rc = minimize_batch(theta_i[0][None, :], evc, **kw)
+            par = self.comm.bcast_host(rc["x"][0], like=like)
+            new_theta_i = np.tile(par, (theta_i.shape[0], 1))
+        else:
+            def evi(x, act):
+                self.stats["indiv_rounds"] += 1
+                return self.be.indiv_eval(x, True, active=act)
+            if self.hi > self.lo:
+                ri = minimize_batch(theta_i[self.lo:self.hi], evi, **kw)
+                loc = ri["x"]
+            else:
+                loc = np.zeros((0, 3))
+            new_theta_i = self.comm.allgather_rows(loc, self.counts, like=like)
+        return new_theta0, new_theta_i
+
+    # ------------------------------------------------------------ EM driver (MG:15-82)
+    def em_iteration(self, theta0, theta_i, m0, common_hp, opt_kw=None):
+        """One pass of the loop body of `training` (MG:32-75) without the stopping logic:
+        E-step, M-step, the two logL_monitoring calls. Returns (new_theta0, new_theta_i,
+        logLL at hp, logLL at new hp)."""
+        pen_e = float(np.mean(theta_i[:, 2]))  # CF:381 (signed mean)
+        self.e_step(theta0, theta_i, pen_e, m0)
+        new_theta0, new_theta_i = self.m_step(theta0, theta_i, common_hp, opt_kw)
+        if np.any(np.isnan(new_theta0)) or np.any(np.isnan(new_theta_i)):
+            return new_theta0, new_theta_i, np.nan, np.nan
+        l_old = self.logL_monitoring(theta0, theta_i)
+        l_new = self.logL_monitoring(new_theta0, new_theta_i)
+        return new_theta0, new_theta_i, l_old, l_new
+
+    def training(self, prior_mean, ini_theta0, ini_theta_i, common_hp=True, n_loop_max=25,
+                 trace=None, opt_kw=None):
+        M = self.ds.M
+        theta0 = np.asarray(ini_theta0, dtype=np.float64).copy()
+        theta_i = np.tile(np.asarray(ini_theta_i, dtype=np.float64), (M, 1))
+        cv = False
+        for it in range(1, n_loop_max + 1):
+            n0, ni, l_old, l_new = self.em_iteration(theta0, theta_i, prior_mean, common_hp,
+                                                     opt_kw)
+            if np.isnan(l_old):  # MG:46-51: keep the last valid iteration
+                break
+            eps = (l_new - l_old) / abs(l_new)
+            if trace is not None:
+                trace.append({"iter": it, "logLL": l_old, "logL_new_hp": l_new, "eps": eps})
+            if eps < 1e-3:  # MG:66-71
+                if eps > 0:
+                    theta0, theta_i = n0, ni
+                cv = True
+                break
+            theta0, theta_i = n0, ni
+        return theta0, theta_i, cv

@@ -1,0 +1,260 @@
+"""GPU parity tests: every HIP entry point against the CPU oracle on the same inputs.
+
+Tolerances (FP64, north star: 1e-8 relative): kernel builds 1e-13; inverses / log-dets 1e-9
+relative to the matrix scale (condition numbers up to ~1e6 in these cases); objective values
+1e-10; gradients 1e-8.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import magma_oracle as orc  # noqa: E402  (checker only)
+from kat_common import dataset, hp_of  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
+    import magma_amd
+    from magma_amd import _lib
+    return {"torch": torch, "lib": _lib.load(), "_lib": _lib, "m": magma_amd}
+
+
+def _stream(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _ragged_db(rng, sizes, tmax=10.0, step=0.05):
+    grid = np.arange(0.0, tmax + 1e-9, step)
+    ids, ts, ys = [], [], []
+    for k, n in enumerate(sizes):
+        t = np.sort(rng.choice(grid, n, replace=False))
+        ids += [k + 1] * n
+        ts.append(t)
+        ys.append(rng.normal(0, 2, n) + 0.5 * t)
+    return {"ID": np.array(ids), "Timestamp": np.concatenate(ts), "Output": np.concatenate(ys)}
+
+
+def _random_hp(rng, ids):
+    return {"theta_0": np.array([rng.uniform(0, 3), rng.uniform(0, 2)]),
+            "theta_i": {i: np.array([rng.uniform(-1, 4), rng.uniform(-0.5, 2), rng.uniform(0.1, 2)])
+                        for i in ids}}
+
+
+# ---------------------------------------------------------------- MFMA tile / dense kernels
+def test_gemm_nt_matches_numpy(gpu):
+    """Asymmetric operands: catches a swapped accumulator row/column map of the f64 MFMA."""
+    torch, _lib = gpu["torch"], gpu["_lib"]
+    rng = np.random.default_rng(0)
+    Mr, Nc, K = 128, 192, 80
+    A = rng.normal(size=(Mr, K))
+    B = rng.normal(size=(Nc, K))
+    C0 = rng.normal(size=(Mr, Nc))
+    dA = torch.from_numpy(A.T.copy()).cuda()  # column-major
+    dB = torch.from_numpy(B.T.copy()).cuda()
+    dC = torch.from_numpy(C0.T.copy()).cuda()
+    _lib.call("magma_gemm_nt", Mr, Nc, K, 1.5, _p(dA), Mr, _p(dB), Nc, -0.5, _p(dC), Mr,
+              _stream(torch))
+    got = dC.cpu().numpy().T
+    exp = 1.5 * A @ B.T - 0.5 * C0
+    assert np.abs(got - exp).max() < 1e-12 * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("N", [1, 37, 64, 65, 200, 450])
+def test_spd_inverse_and_logdet(gpu, N):
+    torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
+    rng = np.random.default_rng(N)
+    X = rng.normal(size=(N, N + 5))
+    A = X @ X.T / N + 0.1 * np.eye(N)
+    Np = lib.magma_pad(N)
+    dA = torch.empty(Np * Np, dtype=torch.float64, device="cuda")
+    src = torch.from_numpy(A.T.copy()).cuda()
+    st = _stream(torch)
+    _lib.call("magma_copy_pad", N, _p(src), N, _p(dA), 0, st)
+    work = torch.empty((lib.magma_workspace_bytes(N) + 7) // 8, dtype=torch.float64, device="cuda")
+    ld = torch.zeros(1, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.call("magma_spd_inverse", N, _p(dA), _p(ld), _p(info), _p(work), st)
+    out = torch.empty(N * N, dtype=torch.float64, device="cuda")
+    _lib.call("magma_copy_unpad", N, _p(dA), _p(out), N, st)
+    got = out.cpu().numpy().reshape(N, N).T
+    exp = np.linalg.inv(A)
+    assert int(info.item()) == 0
+    assert np.abs(got - exp).max() < 1e-10 * np.abs(exp).max()
+    assert abs(ld.item() - np.linalg.slogdet(A)[1]) < 1e-10 * max(1.0, abs(ld.item()))
+    assert np.abs(got - got.T).max() == 0.0  # mirrored store: exactly symmetric
+
+
+def test_spd_inverse_flags_indefinite(gpu):
+    torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
+    N = 70
+    A = np.eye(N)
+    A[40, 40] = -1.0
+    Np = lib.magma_pad(N)
+    dA = torch.empty(Np * Np, dtype=torch.float64, device="cuda")
+    src = torch.from_numpy(A.T.copy()).cuda()
+    st = _stream(torch)
+    _lib.call("magma_copy_pad", N, _p(src), N, _p(dA), 0, st)
+    work = torch.empty((lib.magma_workspace_bytes(N) + 7) // 8, dtype=torch.float64, device="cuda")
+    ld = torch.zeros(1, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.call("magma_spd_inverse", N, _p(dA), _p(ld), _p(info), _p(work), st)
+    assert int(info.item()) == 41
+
+
+# ---------------------------------------------------------------- covariance builders
+def test_kern_to_cov_and_inv_vector_branch(gpu):
+    m = gpu["m"]
+    rng = np.random.default_rng(3)
+    t = rng.choice(np.arange(0, 10, 0.05), 150, replace=False)  # unsorted on purpose
+    lab, K = m.kern_to_cov(t, m.kernel, [1.3, 0.7], 0.4)
+    lab_o, K_o = orc.kern_to_cov(t, orc.kernel, [1.3, 0.7], 0.4)
+    assert np.array_equal(lab, lab_o)
+    assert np.abs(K - K_o).max() < 1e-13 * np.abs(K_o).max()
+    lab, Ki = m.kern_to_inv(t, m.kernel_mu, [1.3, 0.7], 0.4)
+    _, Ki_o = orc.kern_to_inv(t, orc.kernel, [1.3, 0.7], 0.4)
+    assert np.abs(Ki - Ki_o).max() < 1e-9 * np.abs(Ki_o).max()
+
+
+@pytest.mark.parametrize("sizes", [[1, 2, 3, 7, 8, 9, 30, 31, 33, 50, 64], [30] * 5])
+def test_kern_to_cov_and_inv_batched(gpu, sizes):
+    m = gpu["m"]
+    rng = np.random.default_rng(len(sizes))
+    db = _ragged_db(rng, sizes)
+    hp = _random_hp(rng, orc.unique_in_order(db["ID"]))
+    got = m.kern_to_cov(db, m.kernel, hp["theta_i"], 0)
+    exp = orc.kern_to_cov(db, orc.kernel, hp["theta_i"], 0)
+    goti = m.kern_to_inv(db, m.kernel, hp["theta_i"], 0)
+    expi = orc.kern_to_inv(db, orc.kernel, hp["theta_i"], 0)
+    for i in exp:
+        assert np.array_equal(got[i][0], exp[i][0])
+        assert np.abs(got[i][1] - exp[i][1]).max() < 1e-13 * np.abs(exp[i][1]).max()
+        assert np.abs(goti[i][1] - expi[i][1]).max() < 1e-9 * np.abs(expi[i][1]).max(), i
+    # common numeric theta + sigma (CF:89-93)
+    got = m.kern_to_inv(db, m.kernel, [0.5, 1.0], 0.3)
+    exp = orc.kern_to_inv(db, orc.kernel, [0.5, 1.0], 0.3)
+    for i in exp:
+        assert np.abs(got[i][1] - exp[i][1]).max() < 1e-9 * np.abs(exp[i][1]).max()
+
+
+# ---------------------------------------------------------------- E-step
+@pytest.mark.parametrize("sizes", [[30] * 20, [1, 5, 17, 40, 64, 12, 3]])
+def test_e_step_matches_oracle(gpu, sizes):
+    m = gpu["m"]
+    rng = np.random.default_rng(sum(sizes))
+    db = _ragged_db(rng, sizes)
+    hp = _random_hp(rng, orc.unique_in_order(db["ID"]))
+    got = m.e_step(db, 1.5, m.kernel_mu, m.kernel, hp)
+    exp = orc.e_step(db, 1.5, orc.kernel, orc.kernel, hp)
+    assert np.array_equal(got["mean"]["Timestamp"], exp["mean"]["Timestamp"])
+    sc = np.abs(exp["cov"][1]).max()
+    assert np.abs(got["cov"][1] - exp["cov"][1]).max() < 1e-9 * sc
+    assert np.abs(got["mean"]["Output"] - exp["mean"]["Output"]).max() < 1e-9 * np.abs(exp["mean"]["Output"]).max()
+    assert np.abs(got["pred_GP"]["Var"] - exp["pred_GP"]["Var"]).max() < 1e-9 * sc
+
+
+def test_posterior_mu_vector_prior_mean(gpu):
+    m = gpu["m"]
+    truth, test, train = dataset("data_FF", 3)
+    hp = hp_of("hp_FF", 3)
+    got = m.posterior_mu(train, test, truth["Timestamp"][::7], 0.3, m.kernel_mu, m.kernel, hp)
+    exp = orc.posterior_mu(train, test, truth["Timestamp"][::7], 0.3, orc.kernel, orc.kernel, hp)
+    assert np.abs(got["cov"][1] - exp["cov"][1]).max() < 1e-9 * np.abs(exp["cov"][1]).max()
+    assert np.abs(got["mean"]["Output"] - exp["mean"]["Output"]).max() < 1e-9
+
+
+# ---------------------------------------------------------------- M-step objective / gradient
+def _posterior_for(db, hp, m0=0.7):
+    return orc.e_step(db, m0, orc.kernel, orc.kernel, hp)
+
+
+@pytest.mark.parametrize("sizes", [[1, 2, 12, 30, 50, 64], [30] * 4])
+def test_logL_GP_mod_and_gradient_per_individual(gpu, sizes):
+    m = gpu["m"]
+    rng = np.random.default_rng(7 + len(sizes))
+    db = _ragged_db(rng, sizes)
+    ids = orc.unique_in_order(db["ID"])
+    hp = _random_hp(rng, ids)
+    par = _posterior_for(db, hp)
+    labels, cov = par["cov"]
+    for i in ids:
+        sel = db["ID"] == i
+        db_i = {"Timestamp": db["Timestamp"][sel], "Output": db["Output"][sel]}
+        mean_i = orc._mean_at(par["mean"], db_i["Timestamp"])
+        cov_i = orc._block(labels, cov, db_i["Timestamp"])
+        th = hp["theta_i"][i] + rng.normal(0, 0.1, 3)
+        f = m.logL_GP_mod(th, db_i, mean_i, m.kernel, cov_i)
+        g = m.gr_GP_mod(th, db_i, mean_i, m.kernel, cov_i)
+        f_o = orc.logL_GP_mod(th, db_i, mean_i, orc.kernel, cov_i)
+        g_o = orc.gr_GP_mod(th, db_i, mean_i, orc.kernel, cov_i)
+        assert abs(f - f_o) < 1e-10 * max(1.0, abs(f_o)), (i, f, f_o)
+        assert np.abs(g - g_o).max() < 1e-8 * max(1.0, np.abs(g_o).max()), (i, g, g_o)
+        # plain GP likelihood / gradient (train_new_gp's objective)
+        f = m.logL_GP(th, db_i, mean_i, m.kernel, cov_i)
+        g = m.gr_GP(th, db_i, mean_i, m.kernel, cov_i)
+        f_o = orc.logL_GP(th, db_i, mean_i, orc.kernel, cov_i)
+        g_o = orc.gr_GP(th, db_i, mean_i, orc.kernel, cov_i)
+        assert abs(f - f_o) < 1e-10 * max(1.0, abs(f_o))
+        assert np.abs(g - g_o).max() < 1e-8 * max(1.0, np.abs(g_o).max())
+
+
+def test_theta0_objective_and_gradient(gpu):
+    m = gpu["m"]
+    rng = np.random.default_rng(11)
+    db = _ragged_db(rng, [30] * 10)
+    hp = _random_hp(rng, orc.unique_in_order(db["ID"]))
+    par = _posterior_for(db, hp)
+    th0 = np.array([1.2, 0.4])
+    f = m.logL_GP_mod(th0, par["mean"], 0.7, m.kernel_mu, par["cov"][1], pen_diag=0.8)
+    g = m.gr_GP_mod(th0, par["mean"], 0.7, m.kernel_mu, par["cov"][1], pen_diag=0.8)
+    f_o = orc.logL_GP_mod(th0, par["mean"], 0.7, orc.kernel, par["cov"][1], pen_diag=0.8)
+    g_o = orc.gr_GP_mod(th0, par["mean"], np.full(par["mean"]["Output"].size, 0.7), orc.kernel,
+                        par["cov"][1], pen_diag=0.8)
+    assert abs(f - f_o) < 1e-10 * abs(f_o), (f, f_o)
+    assert np.abs(g - g_o).max() < 1e-8 * np.abs(g_o).max(), (g, g_o)
+
+
+def test_common_hp_objective_and_monitoring(gpu):
+    m = gpu["m"]
+    rng = np.random.default_rng(13)
+    db = _ragged_db(rng, [20, 25, 30, 1, 8])
+    ids = orc.unique_in_order(db["ID"])
+    hp = _random_hp(rng, ids)
+    par = _posterior_for(db, hp)
+    th = np.array([0.8, 0.9, 0.5])
+    f = m.logL_GP_mod_common_hp(th, db, par["mean"], m.kernel, par["cov"])
+    g = m.gr_GP_mod_common_hp(th, db, par["mean"], m.kernel, par["cov"])
+    f_o = orc.logL_GP_mod_common_hp(th, db, par["mean"], orc.kernel, par["cov"])
+    g_o = orc.gr_GP_mod_common_hp(th, db, par["mean"], orc.kernel, par["cov"])
+    assert abs(f - f_o) < 1e-10 * abs(f_o)
+    assert np.abs(g - g_o).max() < 1e-8 * np.abs(g_o).max()
+    ll = m.logL_monitoring(hp, db, m.kernel, m.kernel_mu, par["mean"], par["cov"], 0.7)
+    ll_o = orc.logL_monitoring(hp, db, orc.kernel, orc.kernel, par["mean"], par["cov"], 0.7)
+    assert abs(ll - ll_o) < 1e-10 * abs(ll_o)
+
+
+# ---------------------------------------------------------------- prediction
+def test_pred_gp_matches_oracle(gpu):
+    m = gpu["m"]
+    truth, test, train = dataset("data_FT", 5)
+    hp = hp_of("hp_FT", 5)
+    db_obs = {k: v[:20] for k, v in test.items()}
+    ts = test["Timestamp"][20:]
+    mu = orc.posterior_mu(train, db_obs, ts, 0.0, orc.kernel, orc.kernel, hp)
+    got = m.pred_gp(db_obs, ts, mu["mean"], mu["cov"], m.kernel, [1.1, 0.6], 0.3)
+    exp = orc.pred_gp(db_obs, ts, mu["mean"], mu["cov"], orc.kernel, [1.1, 0.6], 0.3)
+    assert np.abs(got["Mean"] - exp["Mean"]).max() < 1e-9 * np.abs(exp["Mean"]).max()
+    assert np.abs(got["Var"] - exp["Var"]).max() < 1e-9 * np.abs(exp["Var"]).max()
+    # plain GP regression: cov_mu NULL, constant mean, default 500-point grid (MG:152-160)
+    got = m.pred_gp(db_obs, None, 2.0, None, m.kernel, [1.1, 0.6], 0.3)
+    exp = orc.pred_gp(db_obs, None, 2.0, None, orc.kernel, [1.1, 0.6], 0.3)
+    assert np.abs(got["Mean"] - exp["Mean"]).max() < 1e-9 * np.abs(exp["Mean"]).max()
+    assert np.abs(got["Var"] - exp["Var"]).max() < 1e-9 * np.abs(exp["Var"]).max()
