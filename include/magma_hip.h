@@ -48,6 +48,14 @@ int magma_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream);
 int magma_memset_zero(void* dst, size_t bytes, void* stream);
 int magma_stream_sync(void* stream);
 
+/* Optional timing of kernel classes with HIP events recorded on the launching stream
+ * (bench.py's roofline figures). ids: 0 T = Kinv C GEMM, 1 theta_0 gradient contraction,
+ * 2 dense SPD inverse (all its launches), 3 per-individual f + gradient, 4 per-individual f
+ * only, 5 E-step scatter, 6 K_0 build, 7 batched K_i build, 8 batched K_i inverse. */
+int magma_prof_enable(int on);
+int magma_prof_reset(void);
+int magma_prof_get(int id, int* h_count, double* h_total_ms);
+
 /* ---- (1) batched SE-kernel covariance ---- */
 /* kern_to_cov, tibble branch (CF:85-112): K_i = SE(t_i; theta_i) + sigma_i^2 I for every
  * individual, written column-major at K_out + off2[i] (off2[i] = sum_{j<i} n_j^2). */
@@ -88,14 +96,15 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
 /* mode 0: logL_GP_mod + gr_GP_mod per individual (CF:181-201, 304-332) with mean = mean[idx],
  * new_cov = cov[idx, idx]; mode 1: logL_GP + gr_GP (CF:174-179, 279-302: covariance K + C).
  * f_out[M], g_out[3M] (already negated like the reference: these are the gradients of f),
- * info_out[M]. active (optional, M bytes): 0 = skip this individual. cov may be NULL (C = 0).
+ * info_out[M], all indexed by individual. sel (optional): nsel int32 indices of the individuals
+ * to evaluate (a lock-step optimiser passes the problems still running); NULL = all M.
+ * cov may be NULL (C = 0).
  * The common-HP objective (CF:203-234, 334-368) is the sum of these over individuals with
  * theta_stride = 0. */
 int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
                      const double* y, const int* idx, const double* theta, int theta_stride,
-                     const double* mean, const double* cov, int N, int want_grad,
-                     const unsigned char* active, double* f_out, double* g_out, int* info_out,
-                     void* stream);
+                     const double* mean, const double* cov, int N, int want_grad, const int* sel,
+                     int nsel, double* f_out, double* g_out, int* info_out, void* stream);
 /* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
  * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
  * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */

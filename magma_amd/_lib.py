@@ -28,14 +28,17 @@ SIGNATURES = {
     "magma_memcpy_d2h": (_i, [_p, _p, _sz, _p]),
     "magma_memset_zero": (_i, [_p, _sz, _p]),
     "magma_stream_sync": (_i, [_p]),
+    "magma_prof_enable": (_i, [_i]),
+    "magma_prof_reset": (_i, []),
+    "magma_prof_get": (_i, [_i, C.POINTER(_i), C.POINTER(_d)]),
     "magma_kern_to_cov_batched": (_i, [_i, _p, _p, _p, _p, _i, _p, _p]),
     "magma_kern_to_cov_grid": (_i, [_i, _p, _d, _d, _d, _p, _p]),
     "magma_kern_to_inv_batched": (_i, [_i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "magma_estep_scatter": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "magma_estep_finish": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _p, _p, C.POINTER(_i), _p]),
     "magma_spd_inverse": (_i, [_i, _p, _p, _p, _p, _p]),
-    "magma_indiv_eval": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p,
-                              _p, _p]),
+    "magma_indiv_eval": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p,
+                              _p, _p, _p]),
     "magma_theta0_eval": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _i, _p, C.POINTER(_d),
                                C.POINTER(_i), _p]),
     "magma_sum": (_i, [_i64, _p, _p, C.POINTER(_d), _p]),

@@ -28,6 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("MAGMA_EXTRA_FLAGS", "").split()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for src in SOURCES:
@@ -36,12 +37,15 @@ def build(force=False, verbose=True):
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
-            jobs.append([hipcc] + FLAGS + lang + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + extra + lang + ["-c", s, "-o", o])
     if jobs:
         def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise subprocess.CalledProcessError(r.returncode, cmd)
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <utility>
+#include <vector>
 
 namespace magma {
 
@@ -49,6 +51,29 @@ struct Work {
 };
 
 static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+// Optional per-kernel-class timing with HIP events on the launching stream (bench.py's
+// roofline figures): off by default, no cost when off.
+enum ProfId { PROF_GEMM = 0, PROF_CONTRACT, PROF_SPD_INVERSE, PROF_INDIV_EVAL, PROF_INDIV_F,
+              PROF_SCATTER, PROF_COV_GRID, PROF_COV_BATCHED, PROF_INV_BATCHED, PROF_N };
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_N];
+
+struct Prof {
+  int id;
+  hipStream_t st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  Prof(int id_, hipStream_t st_) : id(id_), st(st_) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = nullptr; return; }
+    (void)hipEventRecord(e0, st);
+  }
+  ~Prof() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, st);
+    g_prof_ev[id].push_back({e0, e1});
+  }
+};
 
 static int check_small(int M, int nmax) {
   if (M < 0) return fail(2, "M must be >= 0");
@@ -97,6 +122,7 @@ int magma_kern_to_cov_batched(int M, const int64_t* off, const int64_t* off2, co
                               const double* theta, int theta_stride, double* K_out, void* stream) {
   if (M < 0) return fail(2, "M must be >= 0");
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  Prof pf(PROF_COV_BATCHED, S(stream));
   return launch_se_cov_batched(M, off, off2, t, theta, theta_stride, K_out, S(stream));
 }
 
@@ -111,6 +137,7 @@ int magma_kern_to_inv_batched(int M, int nmax, const int64_t* off, const int64_t
                               double* Kinv_out, double* logdet_out, int* info_out, void* stream) {
   if (int rc = check_small(M, nmax)) return rc;
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  Prof pf(PROF_INV_BATCHED, S(stream));
   return launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv_out, logdet_out,
                                info_out, S(stream));
 }
@@ -120,6 +147,7 @@ int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, co
                         double* w, int* info_out, void* stream) {
   if (int rc = check_small(M, nmax)) return rc;
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  Prof pf(PROF_SCATTER, S(stream));
   return launch_estep_scatter(M, nmax, off, t, y, idx, theta, theta_stride, P, magma_pad(N), w,
                               info_out, S(stream));
 }
@@ -128,6 +156,7 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = magma_pad(N);
   Work wk(work, Np);
+  Prof pf(PROF_SPD_INVERSE, S(stream));
   return launch_spd_inverse(Np, A, d_logdet, d_info, wk.inv, S(stream));
 }
 
@@ -140,12 +169,21 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
   hipStream_t st = S(stream);
   Work wk(work, Np);
   int rc;
-  if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
-  if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  {
+    Prof pf(PROF_COV_GRID, st);
+    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+  }
+  {
+    Prof pf(PROF_SPD_INVERSE, st);
+    if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  }
   if ((rc = launch_axpy((int64_t)n2, 1.0, wk.A0, P, st))) return rc;
   if ((rc = launch_symv(Np, wk.A0, m0, wk.tmp, st))) return rc;
   if ((rc = launch_axpy(Np, 1.0, wk.tmp, w, st))) return rc;
-  if ((rc = launch_spd_inverse(Np, P, wk.scal + 5, wk.iinfo + 1, wk.inv, st))) return rc;
+  {
+    Prof pf(PROF_SPD_INVERSE, st);
+    if ((rc = launch_spd_inverse(Np, P, wk.scal + 5, wk.iinfo + 1, wk.inv, st))) return rc;
+  }
   if ((rc = launch_symv(Np, P, w, mean_out, st))) return rc;
   int hinfo[2] = {0, 0};
   MAGMA_CHECK_HIP(hipMemcpyAsync(hinfo, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -156,14 +194,16 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
 
 int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
                      const double* y, const int* idx, const double* theta, int theta_stride,
-                     const double* mean, const double* cov, int N, int want_grad,
-                     const unsigned char* active, double* f_out, double* g_out, int* info_out,
-                     void* stream) {
+                     const double* mean, const double* cov, int N, int want_grad, const int* sel,
+                     int nsel, double* f_out, double* g_out, int* info_out, void* stream) {
   if (int rc = check_small(M, nmax)) return rc;
   if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
-  return launch_indiv_eval(M, nmax, off, t, y, idx, theta, theta_stride, mean, cov, magma_pad(N),
-                           mode, want_grad, active, f_out, g_out, info_out, S(stream));
+  if (sel != nullptr && (nsel < 0 || nsel > M)) return fail(2, "nsel must be in 0..M");
+  const int count = sel ? nsel : M;
+  Prof pf(want_grad ? PROF_INDIV_EVAL : PROF_INDIV_F, S(stream));
+  return launch_indiv_eval(count, sel, nmax, off, t, y, idx, theta, theta_stride, mean, cov,
+                           magma_pad(N), mode, want_grad, f_out, g_out, info_out, S(stream));
 }
 
 int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,
@@ -175,8 +215,14 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
   hipStream_t st = S(stream);
   Work wk(work, Np);
   int rc;
-  if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
-  if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  {
+    Prof pf(PROF_COV_GRID, st);
+    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+  }
+  {
+    Prof pf(PROF_SPD_INVERSE, st);
+    if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  }
   // z = mean - m0 on the true grid, zero on the padding
   MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, mean, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
   if ((rc = launch_axpy(Np, -1.0, m0, wk.z, st))) return rc;
@@ -185,7 +231,11 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
   if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
   if ((rc = launch_dot((int64_t)n2, wk.A0, cov, wk.partials, wk.scal + 2, st))) return rc;
   if (want_grad) {
-    if ((rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st))) return rc;
+    {
+      Prof pf(PROF_GEMM, st);
+      if ((rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st))) return rc;
+    }
+    Prof pf(PROF_CONTRACT, st);
     if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2,
                                      wk.partials, wk.scal + 3, st)))
       return rc;
@@ -219,6 +269,36 @@ int magma_pred_gp(int n, const double* tn, const double* yn, const double* mean_
     return fail(2, "pred_gp: idx_n / idx_t required with cov");
   return launch_pred_gp(n, tn, yn, mean_obs, idx_n, T, ts, mean_pred, idx_t, cov,
                         cov ? magma_pad(N) : 0, theta3, mean_out, var_out, d_info, S(stream));
+}
+
+int magma_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int magma_prof_reset(void) {
+  for (int i = 0; i < PROF_N; ++i) {
+    for (auto& pr : g_prof_ev[i]) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    g_prof_ev[i].clear();
+  }
+  return 0;
+}
+
+int magma_prof_get(int id, int* h_count, double* h_total_ms) {
+  if (id < 0 || id >= PROF_N) return fail(2, "prof id out of range");
+  double tot = 0.0;
+  for (auto& pr : g_prof_ev[id]) {
+    MAGMA_CHECK_HIP(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    MAGMA_CHECK_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+  }
+  *h_count = (int)g_prof_ev[id].size();
+  *h_total_ms = tot;
+  return 0;
 }
 
 int magma_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,

@@ -123,51 +123,117 @@ __global__ __launch_bounds__(256) void se_cov_grid_kernel(int N, int Np,
 // block A_kk in registers/LDS (cheaper than a launch boundary), then workgroup w > 0 solves
 // L_ik = A_ik L_kk^-T for block row i = k + w, and workgroup 0 stores L_kk and solves the
 // same system against the identity, which yields U_kk = L_kk^-T and X_kk = L_kk^-1 (the
-// leaves of the triangular inverse). Thread (row = tid & 63, ty = tid >> 6) owns the 16
-// elements [row][4q + ty] of a block.
+// leaves of the triangular inverse).
+// Thread map: row = 16 * wave + (lane >> 2), ty = lane & 3; a thread owns the 16 elements
+// [row][4q + ty]. A row lives in one quad, so "my row's value of column j" is a DPP quad
+// broadcast; only the factorisation needs LDS + a barrier per column (other rows' values).
+// Reciprocals / reciprocal square roots are v_rcp/v_rsq + Newton steps: no IEEE division or
+// sqrt on the per-column dependency chain.
+template <int SRC>
+__device__ __forceinline__ double quad_bcast_t(double v) {
+  constexpr int ctrl = SRC * 0x55;  // quad_perm: every lane of the quad reads lane SRC
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double quad_bcast(double v, int src) {
+  switch (src & 3) {
+    case 0: return quad_bcast_t<0>(v);
+    case 1: return quad_bcast_t<1>(v);
+    case 2: return quad_bcast_t<2>(v);
+    default: return quad_bcast_t<3>(v);
+  }
+}
+
+__device__ __forceinline__ double fast_rcp_d(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
+
+__device__ __forceinline__ double fast_rsqrt_d(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  return y;
+}
+
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t ld,
                                                           int k, double* __restrict__ X,
                                                           double* __restrict__ U,
                                                           double* __restrict__ logdet,
                                                           int* __restrict__ info) {
+  // The column loops run over 16 quads of 4 columns with the register window ROTATED after
+  // each quad (d[0] is always the quad being eliminated), so the body is a few KB that stays
+  // in the instruction cache; a fully unrolled 64-column body is ~70 KB of straight-line code
+  // and ran instruction-fetch bound (47 us per launch).
   __shared__ double Ls[64 * 65];
-  __shared__ double colbuf[2][64];
-  const int tid = threadIdx.x, row = tid & 63, ty = tid >> 6;
+  __shared__ double colbuf[2][128];  // entries >= 64 are only read into dead registers
+  __shared__ double invd[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = 16 * wave + (lane >> 2), ty = lane & 3;
   const int w = blockIdx.x;
+  const int ldi = (int)ld;  // block-local offsets fit 32 bits (64 columns of one block)
   double* Akk = A + (int64_t)k * NB * (ld + 1);
   double d[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) d[q] = Akk[row + (int64_t)(4 * q + ty) * ld];
+  for (int q = 0; q < 16; ++q) d[q] = Akk[row + (4 * q + ty) * ldi];
+  // B block (A_ik, or the identity for workgroup 0) loaded up front: overlaps the factorisation
+  double b[16];
+  double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
+  if (w == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = (4 * q + ty == row) ? 1.0 : 0.0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = Aik[row + (4 * q + ty) * ldi];
+  }
+  if (tid < 128) {
+    colbuf[0][tid] = 0.0;
+    colbuf[1][tid] = 0.0;
+  }
   double pm = 1.0;  // product of pivots as mantissa * 2^pe (pivot = L_jj^2)
   int pe = 0;
   int bad = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int q0 = 0; q0 < 16; ++q0) {
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    double* cb = colbuf[j & 1];
-    if (ty == (j & 3)) cb[row] = d[j >> 2];
-    __syncthreads();
-    double djj = cb[j];
-    if (!(djj > 0.0) || !(djj < 1.7e308)) {
-      if (bad == 0) bad = j + 1;
-      djj = 1.0;
-    }
-    {
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * q0 + jj;
+      double* cb = colbuf[jj & 1];
+      if (ty == jj) cb[row] = d[0];
+      __syncthreads();
+      double djj = cb[j];
+      const bool ok = (djj > 0.0) && (djj < 1.7e308);
+      bad = (!ok && bad == 0) ? j + 1 : bad;
+      djj = ok ? djj : 1.0;
+      const double own = quad_bcast(d[0], jj);
+      const double f = own * fast_rcp_d(djj);
+      // Branch-free rank-1 update of every column right of j. Elements above the diagonal
+      // (and the dead registers behind column 63) are updated too, with values that are
+      // never read, so that no per-element predicate is needed.
+      const double f0 = (ty > jj) ? f : 0.0;
+      const double* cq = cb + 4 * q0 + ty;
+      d[0] = fma(-f0, cq[0], d[0]);
+#pragma unroll
+      for (int q = 1; q < 16; ++q) d[q] = fma(-f, cq[4 * q], d[q]);
+      // off the dependency chain: L column, 1/L_jj, log-det
+      const double rs = fast_rsqrt_d(djj);
+      if (ty == jj) Ls[row * 65 + j] = (row > j) ? own * rs : ((row == j) ? djj * rs : 0.0);
+      if (tid == 0) invd[j] = rs;
       int e;
       pm *= frexp(djj, &e);
       pe += e;
     }
-    const double s = sqrt(djj);
-    const double own = cb[row];
-    if (ty == (j & 3)) Ls[row * 65 + j] = (row > j) ? own / s : ((row == j) ? s : 0.0);
-    const double f = own / djj;
 #pragma unroll
-    for (int q = (j >> 2); q < 16; ++q) {
-      const int c = 4 * q + ty;
-      d[q] = (c > j && c <= row) ? fma(-f, cb[c], d[q]) : d[q];  // select: a branch here crashes hipcc 7.2
-    }
+    for (int q = 0; q < 15; ++q) d[q] = d[q + 1];
+    d[15] = 0.0;
   }
   __syncthreads();
-  double b[16];
   if (w == 0) {
     if (tid == 0) {
       logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
@@ -176,44 +242,39 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int c = 4 * q + ty;
-      Akk[row + (int64_t)c * ld] = Ls[row * 65 + c];
-      b[q] = (c == row) ? 1.0 : 0.0;
-    }
-  } else {
-    const double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) b[q] = Aik[row + (int64_t)(4 * q + ty) * ld];
-  }
-  // X L^T = B, column by column
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    double* cb = colbuf[j & 1];
-    if (ty == (j & 3)) {
-      const double x = b[j >> 2] / Ls[j * 65 + j];
-      b[j >> 2] = x;
-      cb[row] = x;
-    }
-    __syncthreads();
-    const double x = cb[row];
-#pragma unroll
-    for (int q = (j >> 2); q < 16; ++q) {
-      const int c = 4 * q + ty;
-      b[q] = (c > j) ? fma(-x, Ls[c * 65 + j], b[q]) : b[q];
+      Akk[row + c * ldi] = Ls[row * 65 + c];
     }
   }
-  if (w == 0) {
-    double* Ukk = U + (int64_t)k * NB * (ld + 1);
-    double* Xkk = X + (int64_t)k * NB * (ld + 1);
+  // X L^T = B, column by column; rows are independent and each row sits in one quad, so this
+  // phase needs no barrier. b[0] is final once its quad is done and is stored right away.
+  double* Ukk = U + (int64_t)k * NB * (ld + 1);
+  double* Xkk = X + (int64_t)k * NB * (ld + 1);
+#pragma unroll 1
+  for (int q0 = 0; q0 < 16; ++q0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int c = 4 * q + ty;
-      Ukk[row + (int64_t)c * ld] = b[q];
-      Xkk[c + (int64_t)row * ld] = b[q];
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * q0 + jj;
+      const double xo = b[0] * invd[j];
+      b[0] = (ty == jj) ? xo : b[0];
+      const double x = quad_bcast(xo, jj);
+      const double x0 = (ty > jj) ? x : 0.0;
+      b[0] = fma(-x0, Ls[(4 * q0 + ty) * 65 + j], b[0]);
+#pragma unroll
+      for (int q = 1; q < 16; ++q) {
+        const int c = min(4 * (q0 + q) + ty, 63);  // clamped rows feed dead registers only
+        b[q] = fma(-x, Ls[c * 65 + j], b[q]);
+      }
     }
-  } else {
-    double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
+    const int c = 4 * q0 + ty;
+    if (w == 0) {
+      Ukk[row + c * ldi] = b[0];
+      Xkk[c + row * ldi] = b[0];
+    } else {
+      Aik[row + c * ldi] = b[0];
+    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Aik[row + (int64_t)(4 * q + ty) * ld] = b[q];
+    for (int q = 0; q < 15; ++q) b[q] = b[q + 1];
+    b[15] = 0.0;
   }
 }
 

@@ -40,6 +40,7 @@ struct LineSearch {
   bool brackt;
   int stage;
   double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+  double cap;  // smallest step at which the objective was non-finite (+inf if none)
 };
 
 // MINPACK-2 dcstep: safeguarded cubic/quadratic step, updates the interval of uncertainty.
@@ -146,6 +147,7 @@ void dcsrch_start(LineSearch& ls, double f, double g, double stp) {
   ls.gy = ls.ginit;
   ls.stmin = 0.0;
   ls.stmax = stp + 4.0 * stp;
+  ls.cap = std::numeric_limits<double>::infinity();
 }
 
 // One More-Thuente iteration with the values (f, g) at step stp; returns the next task and,
@@ -292,8 +294,32 @@ struct magma_lbfgsb {
   void tell_one(int b, double fv, const double* gv) {
     Problem& p = pr[b];
     p.nfev++;
-    if (!std::isfinite(fv)) {
-      p.status = 5;
+    bool finite = std::isfinite(fv);
+    for (int i = 0; i < d && finite; ++i) finite = std::isfinite(gv[i]);
+    if (!finite) {
+      if (p.phase == 0) {  // cannot start: R's driver raises an error here
+        p.status = 5;
+        return;
+      }
+      // Non-finite trial point inside a line search (a covariance that is not numerically
+      // positive definite). R's LU-based solve() returns finite garbage there and the search
+      // backs off; here the step is bisected towards the best point so far and capped.
+      p.ls.cap = std::min(p.ls.cap, p.stp);
+      p.stp = p.ls.stx + 0.5 * (p.stp - p.ls.stx);
+      p.ifun++;
+      p.iback = p.ifun - 1;
+      if (p.iback >= MAXLS) {
+        if (p.col == 0) {
+          p.status = 4;
+          return;
+        }
+        p.col = 0;
+        p.head = 0;
+        p.theta = 1.0;
+        begin_iteration(b);
+        return;
+      }
+      set_trial(b);
       return;
     }
     if (p.phase == 0) {
@@ -314,6 +340,7 @@ struct magma_lbfgsb {
     double stp = p.stp;
     const Task task = dcsrch_step(p.ls, fv, p.gd, stp);
     if (task == TASK_FG) {
+      if (stp >= p.ls.cap) stp = p.ls.stx + 0.5 * (p.ls.cap - p.ls.stx);
       p.stp = stp;
       p.ifun++;
       p.iback = p.ifun - 1;

@@ -22,6 +22,10 @@
 
 namespace magma {
 
+#ifndef MAGMA_INDIV_WAVES
+#define MAGMA_INDIV_WAVES 1
+#endif
+
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
 // ------------------------------------------------------------------ row build
@@ -40,6 +44,15 @@ __device__ __forceinline__ void build_row(double (&a)[NMAX], int lane, int n, do
     // keep the unrolled exp() bodies sequential: interleaving all of them spills registers
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// 1/d by v_rcp_f64 + two Newton steps (<= 2 ulp): keeps a full IEEE division off the
+// serial pivot chain.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
 }
 
 // ------------------------------------------------------------------ symmetric sweep
@@ -65,7 +78,7 @@ __device__ __forceinline__ void sweep_inverse(double (&a)[NMAX], int lane, doubl
     int e;
     pm *= frexp(d, &e);
     pe += e;
-    const double pinv = 1.0 / d;
+    const double pinv = fast_rcp(d);
     const bool isk = (lane == k);
     const double f = isk ? 0.0 : a[k] * pinv;
 #pragma unroll
@@ -197,34 +210,36 @@ __global__ __launch_bounds__(64) void estep_scatter_kernel(
 //        W = aa' + K^-1 C K^-1 - K^-1, g = -(1/2 sum W o K_nl, 1/2 sum W o dK2, sigma tr W).
 // mode 1 (logL_GP / gr_GP): K = K(theta, sigma) + C; f without the trace term; W = aa' - K^-1.
 // C = cov[idx, idx] gathered from the N x N hyper-posterior covariance (cov == nullptr: zero).
-// LDS (dynamic, gradient only): Ks = K^-1 (symmetric, so "own row" and "broadcast row"
-// layouts coincide) and Cs = C, later overwritten by T' = C K^-1.
+// Workgroup b handles individual sel[b] (sel == nullptr: b), so a lock-step optimiser only
+// launches the problems that are still running.
+// Gradient data flow (one LDS matrix, dynamic): Ks = K^-1 (symmetric: "own element" and
+// "broadcast row" layouts coincide). T' = C K^-1 is accumulated in registers with the own
+// operand C[r][c] gathered straight from the L2-resident cov, then written over Ks as rows;
+// Z = K^-1 T' uses the register-resident row of K^-1 as own operand and broadcast rows of T'.
 template <int NMAX>
-__global__ __launch_bounds__(64) void indiv_eval_kernel(
-    int M, const int64_t* __restrict__ off, const double* __restrict__ t,
-    const double* __restrict__ y, const int* __restrict__ idx,
+__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
+    int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
+    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
     const double* __restrict__ cov, int64_t ldc, int mode, int want_grad,
-    const unsigned char* __restrict__ active, double* __restrict__ f_out,
-    double* __restrict__ g_out, int* __restrict__ info_out) {
+    double* __restrict__ f_out, double* __restrict__ g_out, int* __restrict__ info_out) {
   constexpr int LD = NMAX + 2;
   __shared__ double tbuf[64];
   __shared__ double zbuf[64];
   __shared__ double abuf[64];
   __shared__ int ibuf[64];
   __shared__ __attribute__((aligned(16))) double colbuf[64];
-  extern __shared__ __attribute__((aligned(16))) double dyn[];
-  double* Ks = dyn;
-  double* Cs = dyn + NMAX * LD;
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
 
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (active != nullptr && active[i] == 0) return;
+  const int lane = threadIdx.x;
+  const int i = sel ? sel[blockIdx.x] : blockIdx.x;
   const int64_t o = off[i];
   const int n = (int)(off[i + 1] - o);
   const double* th = theta + (int64_t)i * tstride;
   const double sigma = th[2];
   const SEParams p = se_params(th[0], th[1], sigma);
   const bool rv = lane < n;
+  const bool lv = lane < NMAX;  // lanes beyond the padded matrix own no row
   const double tr = rv ? t[o + lane] : 0.0;
   const int ir = rv ? idx[o + lane] : 0;
   const double zr = rv ? (y[o + lane] - mean[ir]) : 0.0;
@@ -236,10 +251,11 @@ __global__ __launch_bounds__(64) void indiv_eval_kernel(
   double a[NMAX];
   build_row<NMAX>(a, lane, n, tr, tbuf, p);
   const bool have_c = (cov != nullptr);
+  const double* crow = cov + ir;  // column-major symmetric: C[r][c] = cov[idx_c * ldc + idx_r]
   if (mode == 1 && have_c) {
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
-      if (rv && c < n) a[c] += cov[(int64_t)ibuf[c] * ldc + ir];
+      if (rv && c < n) a[c] += crow[(int64_t)ibuf[c] * ldc];
   }
   double logdet;
   int info;
@@ -250,66 +266,71 @@ __global__ __launch_bounds__(64) void indiv_eval_kernel(
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) alpha = fma(a[c], zbuf[c], alpha);
   abuf[lane] = alpha;
-  double ssq = wave_sum(zr * alpha);
+  const double ssq = wave_sum(zr * alpha);
 
-  // trace term 1/2 sum(K^-1 o C) (mode 0) and staging of C / K^-1 for the gradient
-  double cor = 0.0;
   const bool grad_c = want_grad && mode == 0 && have_c;
-  const bool lv = lane < NMAX;  // lanes beyond the padded matrix own no row
-  if (mode == 0 && have_c) {
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) {
-      double cv = (rv && c < n) ? cov[(int64_t)ibuf[c] * ldc + ir] : 0.0;
-      cor = fma(a[c], cv, cor);
-      if (grad_c && lv) Cs[c * LD + lane] = cv;
-    }
-    cor = wave_sum(cor);
-  }
-  const double f = 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor;
-  if (lane == 0) {
-    f_out[i] = (info == 0) ? f : __longlong_as_double(0x7ff8000000000000LL);
-    info_out[i] = info;
-  }
-  if (!want_grad) return;
-
+  double cor = 0.0;
   double z[NMAX];  // row r of K^-1 C K^-1 (zero when there is no C term)
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) z[c] = 0.0;
+  if (mode == 0 && have_c && !grad_c) {
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+      const double cv = (rv && c < n) ? crow[(int64_t)ibuf[c] * ldc] : 0.0;
+      cor = fma(a[c], cv, cor);
+    }
+  }
   if (grad_c) {
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
       if (lv) Ks[c * LD + lane] = a[c];
     __syncthreads();
-    // T'[r][d] = sum_c C[r][c] K^-1[c][d]
+    // T'[r][d] = sum_c C[r][c] K^-1[c][d], trace term on the way; own C prefetched 2 ahead
+    double cv0 = (rv && 0 < n) ? crow[(int64_t)ibuf[0] * ldc] : 0.0;
+    double cv1 = (rv && 1 < n) ? crow[(int64_t)ibuf[1] * ldc] : 0.0;
     for (int c = 0; c < n; ++c) {
-      const double cown = lv ? Cs[c * LD + lane] : 0.0;
+      const double cv = cv0;
+      cv0 = cv1;
+      cv1 = (rv && c + 2 < n) ? crow[(int64_t)ibuf[c + 2] * ldc] : 0.0;
+      const double kown = lv ? Ks[c * LD + lane] : 0.0;
+      cor = fma(kown, cv, cor);
       const double* krow = &Ks[c * LD];
 #pragma unroll
       for (int d = 0; d < NMAX; d += 2) {
-        double2 kk = *reinterpret_cast<const double2*>(&krow[d]);
-        z[d] = fma(cown, kk.x, z[d]);
-        z[d + 1] = fma(cown, kk.y, z[d + 1]);
+        const double2 kk = *reinterpret_cast<const double2*>(&krow[d]);
+        z[d] = fma(cv, kk.x, z[d]);
+        z[d + 1] = fma(cv, kk.y, z[d + 1]);
       }
+    }
+    __syncthreads();
+    // rows of T' over Ks (lane d writes row d), then Z[r][b] = sum_d K^-1[r][d] T'[d][b]
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+      if (lv) Ks[lane * LD + b] = z[b];
+      z[b] = 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < NMAX; ++d) {
-      if (lv) Cs[d * LD + lane] = z[d];  // Ts[d][r] = T'[r][d]
-      z[d] = 0.0;
-    }
-    __syncthreads();
-    // Z[r][b] = sum_d T'[d][r] K^-1[d][b]
-    for (int d = 0; d < n; ++d) {
-      const double town = lv ? Cs[lane * LD + d] : 0.0;
-      const double* krow = &Ks[d * LD];
+      const double kown = a[d];
+      const double* trow = &Ks[d * LD];
 #pragma unroll
       for (int b = 0; b < NMAX; b += 2) {
-        double2 kk = *reinterpret_cast<const double2*>(&krow[b]);
-        z[b] = fma(town, kk.x, z[b]);
-        z[b + 1] = fma(town, kk.y, z[b + 1]);
+        const double2 tt = *reinterpret_cast<const double2*>(&trow[b]);
+        z[b] = fma(kown, tt.x, z[b]);
+        z[b + 1] = fma(kown, tt.y, z[b + 1]);
       }
+      __builtin_amdgcn_sched_barrier(0);  // no load hoisting across rows: register pressure
     }
   }
+  if (mode == 0 && have_c) cor = wave_sum(cor);
+  const double f = 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  if (lane == 0) {
+    f_out[i] = (info == 0) ? f : nanv;
+    info_out[i] = info;
+  }
+  if (!want_grad) return;
   __syncthreads();  // abuf visible
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -323,12 +344,12 @@ __global__ __launch_bounds__(64) void indiv_eval_kernel(
     s1 += wk;
     s2 = fma(wk, gq, s2);  // dK/dtheta2 = gq * K_nl, zero on the diagonal (gq = 0 there)
     s3 += (b == lane && rv) ? W : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   s3 = wave_sum(s3);
   if (lane == 0) {
-    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     g_out[3 * (int64_t)i + 0] = (info == 0) ? -0.5 * s1 : nanv;
     g_out[3 * (int64_t)i + 1] = (info == 0) ? -0.5 * s2 : nanv;
     g_out[3 * (int64_t)i + 2] = (info == 0) ? -sigma * s3 : nanv;
@@ -411,6 +432,7 @@ __global__ __launch_bounds__(64) void pred_gp_kernel(
     else if ((nmax) <= 32) { CALL(32); }                \
     else if ((nmax) <= 40) { CALL(40); }                \
     else if ((nmax) <= 48) { CALL(48); }                \
+    else if ((nmax) <= 52) { CALL(52); }                \
     else if ((nmax) <= 56) { CALL(56); }                \
     else { CALL(64); }                                  \
   } while (0)
@@ -449,35 +471,32 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
 }
 
 template <int NM>
-static int launch_indiv_eval_t(int M, const int64_t* off, const double* t, const double* y,
-                               const int* idx, const double* theta, int tstride,
+static int launch_indiv_eval_t(int nsel, const int* sel, const int64_t* off, const double* t,
+                               const double* y, const int* idx, const double* theta, int tstride,
                                const double* mean, const double* cov, int64_t ldc, int mode,
-                               int want_grad, const unsigned char* active, double* f, double* g,
-                               int* info, hipStream_t st) {
-  size_t dyn = 0;
-  if (want_grad && mode == 0 && cov != nullptr) dyn = 2 * (size_t)NM * (NM + 2) * sizeof(double);
+                               int want_grad, double* f, double* g, int* info, hipStream_t st) {
+  const size_t full = (size_t)NM * (NM + 2) * sizeof(double);
+  const size_t dyn = (want_grad && mode == 0 && cov != nullptr) ? full : 0;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)(2 * (size_t)NM * (NM + 2) * sizeof(double)));
+    (void)hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)full);
     attr_set = true;
   }
-  hipLaunchKernelGGL(indiv_eval_kernel<NM>, dim3(M), dim3(64), dyn, st, M, off, t, y, idx,
-                     theta, tstride, mean, cov, ldc, mode, want_grad, active, f, g, info);
+  hipLaunchKernelGGL(indiv_eval_kernel<NM>, dim3(nsel), dim3(64), dyn, st, nsel, sel, off, t, y,
+                     idx, theta, tstride, mean, cov, ldc, mode, want_grad, f, g, info);
   return check_hip(hipGetLastError(), "indiv_eval");
 }
 
-int launch_indiv_eval(int M, int nmax, const int64_t* off, const double* t, const double* y,
-                      const int* idx, const double* theta, int tstride, const double* mean,
-                      const double* cov, int64_t ldc, int mode, int want_grad,
-                      const unsigned char* active, double* f, double* g, int* info,
-                      hipStream_t st) {
-  if (M <= 0) return 0;
+int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, const double* t,
+                      const double* y, const int* idx, const double* theta, int tstride,
+                      const double* mean, const double* cov, int64_t ldc, int mode, int want_grad,
+                      double* f, double* g, int* info, hipStream_t st) {
+  if (nsel <= 0) return 0;
   int rc = 0;
-#define CALL(NM)                                                                             \
-  rc = launch_indiv_eval_t<NM>(M, off, t, y, idx, theta, tstride, mean, cov, ldc, mode,     \
-                               want_grad, active, f, g, info, st)
+#define CALL(NM)                                                                              \
+  rc = launch_indiv_eval_t<NM>(nsel, sel, off, t, y, idx, theta, tstride, mean, cov, ldc,    \
+                               mode, want_grad, f, g, info, st)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return rc;

@@ -118,7 +118,7 @@ class HipBackend:
         self.f = torch.zeros(Mb, dtype=f64, device=dev)
         self.g = torch.zeros(Mb * 3, dtype=f64, device=dev)
         self.info = torch.zeros(Mb, dtype=torch.int32, device=dev)
-        self.active = torch.ones(Mb, dtype=torch.uint8, device=dev)
+        self.sel = torch.zeros(Mb, dtype=torch.int32, device=dev)
         self.P = torch.zeros(self.Np * self.Np, dtype=f64, device=dev)  # precision, then cov
         self.w = torch.zeros(self.Np, dtype=f64, device=dev)
         self.mean = torch.zeros(self.Np, dtype=f64, device=dev)
@@ -126,6 +126,7 @@ class HipBackend:
         wbytes = int(self.lib.magma_workspace_bytes(ds.N))
         self.work = torch.empty((wbytes + 7) // 8, dtype=f64, device=dev)
         self.cov = self.P  # alias: after estep_finish P holds the covariance
+        self.n_evals = 0  # individual objective evaluations launched (for roofline figures)
 
     # -- plumbing
     def stream(self):
@@ -190,15 +191,20 @@ class HipBackend:
         if self.M == 0:
             return np.zeros(0), (np.zeros((0, 3)) if want_grad else None)
         stride = self._set_theta(theta)
-        act = None
+        sel, nsel = None, 0
         if active is not None:
-            self.active[:self.M].copy_(self.torch.from_numpy(
-                np.ascontiguousarray(active, dtype=np.uint8)))
-            act = self.active
+            ids = np.nonzero(active)[0].astype(np.int32)
+            nsel = int(ids.size)
+            if nsel == 0:
+                return np.zeros(self.M), (np.zeros((self.M, 3)) if want_grad else None)
+            if nsel < self.M:
+                self.sel[:nsel].copy_(self.torch.from_numpy(ids))
+                sel = self.sel
+        self.n_evals += nsel if sel is not None else self.M
         _lib.call("magma_indiv_eval", int(mode), self.M, self.nmax, _ptr(self.off), _ptr(self.t),
                   _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, _ptr(self.mean),
-                  _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(act),
-                  _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
+                  _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(sel),
+                  nsel, _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
         f = self.f[:self.M].cpu().numpy()
         g = self.g[:3 * self.M].cpu().numpy().reshape(self.M, 3) if want_grad else None
         return f, g
