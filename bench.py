@@ -134,6 +134,7 @@ def main():
         theta0, theta_i, _, _ = step(theta0, theta_i)
     for k in eng.stats:
         eng.stats[k] = 0
+    eng.be.n_evals = 0
     lib.magma_prof_reset()
     lib.magma_prof_enable(1)
     barrier()
@@ -168,7 +169,10 @@ def main():
             "gemm_nt(T=Kinv*C)": ("mfma", 2.0 * N ** 3, "TFLOP/s"),
             "theta0_contract": ("mfma", 2.0 * N ** 3, "TFLOP/s"),  # Z = T Kinv, 2N^3 (symmetric half skipped)
             "spd_inverse": ("mfma", 1.0 * N ** 3, "TFLOP/s"),
-            "indiv_eval(f+grad)": ("mfma", 5.0 * S3, "TFLOP/s"),
+            # per launch: 5 n^3 flops x the individuals actually evaluated (active list)
+            "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * eng.be.n_evals
+                                   / max(1, prof.get("indiv_eval(f+grad)", {}).get("launches", 1)),
+                                   "TFLOP/s"),
             "indiv_eval(f)": ("mfma", 1.0 * S3, "TFLOP/s"),
             "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n, "GB/s"),
         }
@@ -182,7 +186,8 @@ def main():
                 ach, peak = work / t_s / 1e9, PEAK_HBM_GBS
             roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": ach / peak, "traffic": None,
-                    "avg_launch_ms": prof[dom]["avg_ms"], "launches": prof[dom]["launches"]}
+                    "avg_launch_ms": prof[dom]["avg_ms"], "launches": prof[dom]["launches"],
+                    "share_of_step_time": prof[dom]["total_ms"] / (1e3 * elapsed)}
         e0 = eng.stats["theta0_evals"] / args.steps
         ei = (eng.stats["common_evals"] if common else eng.stats["indiv_rounds"]) / args.steps
         out = {

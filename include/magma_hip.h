@@ -96,8 +96,9 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
 /* mode 0: logL_GP_mod + gr_GP_mod per individual (CF:181-201, 304-332) with mean = mean[idx],
  * new_cov = cov[idx, idx]; mode 1: logL_GP + gr_GP (CF:174-179, 279-302: covariance K + C).
  * f_out[M], g_out[3M] (already negated like the reference: these are the gradients of f),
- * info_out[M], all indexed by individual. sel (optional): nsel int32 indices of the individuals
- * to evaluate (a lock-step optimiser passes the problems still running); NULL = all M.
+ * info_out[M]. sel (optional): nsel int32 indices of the individuals to evaluate (a lock-step
+ * optimiser passes the problems still running); then theta, f_out, g_out and info_out are
+ * COMPACT: slot b belongs to individual sel[b]. NULL = all M, slot = individual.
  * cov may be NULL (C = 0).
  * The common-HP objective (CF:203-234, 334-368) is the sum of these over individuals with
  * theta_stride = 0. */

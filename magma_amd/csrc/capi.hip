@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -57,6 +58,7 @@ static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 enum ProfId { PROF_GEMM = 0, PROF_CONTRACT, PROF_SPD_INVERSE, PROF_INDIV_EVAL, PROF_INDIV_F,
               PROF_SCATTER, PROF_COV_GRID, PROF_COV_BATCHED, PROF_INV_BATCHED, PROF_N };
 static bool g_prof_on = false;
+static std::mutex g_prof_mu;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_N];
 
 struct Prof {
@@ -71,6 +73,7 @@ struct Prof {
   ~Prof() {
     if (!e0) return;
     (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_ev[id].push_back({e0, e1});
   }
 };

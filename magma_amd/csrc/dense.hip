@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
                                                           int* __restrict__ info) {
   // The column loops run over 16 quads of 4 columns with the register window ROTATED after
   // each quad (d[0] is always the quad being eliminated), so the body is a few KB that stays
-  // in the instruction cache; a fully unrolled 64-column body is ~70 KB of straight-line code
-  // and ran instruction-fetch bound (47 us per launch).
-  __shared__ double Ls[64 * 65];
-  __shared__ double colbuf[2][128];  // entries >= 64 are only read into dead registers
+  // in the instruction cache (a fully unrolled 64-column body is ~70 KB of straight-line code
+  // and ran instruction-fetch bound). Each wavefront issues the whole column step on its own
+  // SIMD, so the per-column instruction count is what sets the time: the loop keeps only the
+  // rank-1 update; scaling by 1/L_jj, the log-det and the SPD check are vector passes after it.
+  __shared__ double Ls[128 * 65];    // rows >= 64 are only read into dead registers
+  __shared__ double colbuf[2][128];  // entries >= 64 likewise
+  __shared__ double piv[64];
   __shared__ double invd[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = 16 * wave + (lane >> 2), ty = lane & 3;
@@ -195,22 +198,21 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     colbuf[0][tid] = 0.0;
     colbuf[1][tid] = 0.0;
   }
-  double pm = 1.0;  // product of pivots as mantissa * 2^pe (pivot = L_jj^2)
-  int pe = 0;
-  int bad = 0;
+  for (int e = tid; e < 64 * 65; e += 256) Ls[64 * 65 + e] = 0.0;
   __syncthreads();
+#ifndef MAGMA_DBG_SKIP_FACTOR
 #pragma unroll 1
   for (int q0 = 0; q0 < 16; ++q0) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = 4 * q0 + jj;
       double* cb = colbuf[jj & 1];
-      if (ty == jj) cb[row] = d[0];
+      if (ty == jj) {
+        cb[row] = d[0];
+        Ls[row * 65 + j] = d[0];  // unscaled column j (rows >= j are final); scaled below
+      }
       __syncthreads();
-      double djj = cb[j];
-      const bool ok = (djj > 0.0) && (djj < 1.7e308);
-      bad = (!ok && bad == 0) ? j + 1 : bad;
-      djj = ok ? djj : 1.0;
+      const double djj = cb[j];
       const double own = quad_bcast(d[0], jj);
       const double f = own * fast_rcp_d(djj);
       // Branch-free rank-1 update of every column right of j. Elements above the diagonal
@@ -221,49 +223,59 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
       d[0] = fma(-f0, cq[0], d[0]);
 #pragma unroll
       for (int q = 1; q < 16; ++q) d[q] = fma(-f, cq[4 * q], d[q]);
-      // off the dependency chain: L column, 1/L_jj, log-det
-      const double rs = fast_rsqrt_d(djj);
-      if (ty == jj) Ls[row * 65 + j] = (row > j) ? own * rs : ((row == j) ? djj * rs : 0.0);
-      if (tid == 0) invd[j] = rs;
-      int e;
-      pm *= frexp(djj, &e);
-      pe += e;
+      if (tid == 0) piv[j] = djj;
     }
 #pragma unroll
     for (int q = 0; q < 15; ++q) d[q] = d[q + 1];
     d[15] = 0.0;
   }
+#endif
   __syncthreads();
-  if (w == 0) {
-    if (tid == 0) {
-      logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
-      if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int c = 4 * q + ty;
-      Akk[row + c * ldi] = Ls[row * 65 + c];
+  // pivots -> 1/L_jj, SPD check and log-det (first wavefront); then L = columns * 1/L_jj
+  if (wave == 0) {
+    const double pj = piv[lane];
+    const bool ok = (pj > 0.0) && (pj < 1.7e308);
+    invd[lane] = fast_rsqrt_d(ok ? pj : 1.0);
+    if (w == 0) {
+      const unsigned long long badmask = __ballot(!ok);
+      int e;
+      const double m = frexp(ok ? pj : 1.0, &e);
+      double lg = log(m) + (double)e * 0.69314718055994530941723212145818;
+      lg = wave_sum(lg);
+      if (lane == 0) {
+        logdet[0] += lg;
+        if (badmask != 0ull && info[0] == 0) info[0] = k * NB + __ffsll((long long)badmask);
+      }
     }
   }
+  __syncthreads();
+  // L_kk is NOT written back over A_kk: the other workgroups of this launch re-factor A_kk
+  // from global memory and may start after this point; nothing downstream reads L_kk (the
+  // triangular inverse starts from U_kk / X_kk below).
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = 4 * q + ty;
+    const double v = Ls[row * 65 + c] * invd[c];
+    Ls[row * 65 + c] = (row >= c) ? v : 0.0;
+  }
+  __syncthreads();
   // X L^T = B, column by column; rows are independent and each row sits in one quad, so this
   // phase needs no barrier. b[0] is final once its quad is done and is stored right away.
   double* Ukk = U + (int64_t)k * NB * (ld + 1);
   double* Xkk = X + (int64_t)k * NB * (ld + 1);
+#ifndef MAGMA_DBG_SKIP_TRSM
 #pragma unroll 1
   for (int q0 = 0; q0 < 16; ++q0) {
+    const double* lq = Ls + (4 * q0 + ty) * 65 + 4 * q0;  // L[4 q0 + ty][4 q0]
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const int j = 4 * q0 + jj;
-      const double xo = b[0] * invd[j];
+      const double xo = b[0] * invd[4 * q0 + jj];
       b[0] = (ty == jj) ? xo : b[0];
       const double x = quad_bcast(xo, jj);
       const double x0 = (ty > jj) ? x : 0.0;
-      b[0] = fma(-x0, Ls[(4 * q0 + ty) * 65 + j], b[0]);
+      b[0] = fma(-x0, lq[jj], b[0]);
 #pragma unroll
-      for (int q = 1; q < 16; ++q) {
-        const int c = min(4 * (q0 + q) + ty, 63);  // clamped rows feed dead registers only
-        b[q] = fma(-x, Ls[c * 65 + j], b[q]);
-      }
+      for (int q = 1; q < 16; ++q) b[q] = fma(-x, lq[q * 4 * 65 + jj], b[q]);
     }
     const int c = 4 * q0 + ty;
     if (w == 0) {
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     for (int q = 0; q < 15; ++q) b[q] = b[q + 1];
     b[15] = 0.0;
   }
+#endif
 }
 
 // ------------------------------------------------------------------ trailing update

@@ -232,10 +232,11 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
   extern __shared__ __attribute__((aligned(16))) double Ks[];
 
   const int lane = threadIdx.x;
-  const int i = sel ? sel[blockIdx.x] : blockIdx.x;
+  const int io = blockIdx.x;  // slot of theta / f / g / info (compact when sel is given)
+  const int i = sel ? sel[io] : io;
   const int64_t o = off[i];
   const int n = (int)(off[i + 1] - o);
-  const double* th = theta + (int64_t)i * tstride;
+  const double* th = theta + (int64_t)io * tstride;
   const double sigma = th[2];
   const SEParams p = se_params(th[0], th[1], sigma);
   const bool rv = lane < n;
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
   const double f = 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
   if (lane == 0) {
-    f_out[i] = (info == 0) ? f : nanv;
-    info_out[i] = info;
+    f_out[io] = (info == 0) ? f : nanv;
+    info_out[io] = info;
   }
   if (!want_grad) return;
   __syncthreads();  // abuf visible
@@ -350,9 +351,9 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
   s2 = wave_sum(s2);
   s3 = wave_sum(s3);
   if (lane == 0) {
-    g_out[3 * (int64_t)i + 0] = (info == 0) ? -0.5 * s1 : nanv;
-    g_out[3 * (int64_t)i + 1] = (info == 0) ? -0.5 * s2 : nanv;
-    g_out[3 * (int64_t)i + 2] = (info == 0) ? -sigma * s3 : nanv;
+    g_out[3 * (int64_t)io + 0] = (info == 0) ? -0.5 * s1 : nanv;
+    g_out[3 * (int64_t)io + 1] = (info == 0) ? -0.5 * s2 : nanv;
+    g_out[3 * (int64_t)io + 2] = (info == 0) ? -sigma * s3 : nanv;
   }
 }
 

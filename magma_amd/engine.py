@@ -99,6 +99,8 @@ class HipBackend:
             raise _lib.MagmaHipError("no GPU visible: the HIP path has no CPU fallback")
         self.lib = _lib.load()
         self.dev = torch.device(device if device is not None else "cuda")
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.N = ds.N
         self.Np = int(self.lib.magma_pad(ds.N))
         self.M = hi - lo
@@ -127,6 +129,7 @@ class HipBackend:
         self.work = torch.empty((wbytes + 7) // 8, dtype=f64, device=dev)
         self.cov = self.P  # alias: after estep_finish P holds the covariance
         self.n_evals = 0  # individual objective evaluations launched (for roofline figures)
+        self._side = None
 
     # -- plumbing
     def stream(self):
@@ -134,6 +137,34 @@ class HipBackend:
 
     def sync(self):
         self.torch.cuda.current_stream(self.dev).synchronize()
+
+    def run_aside(self, fn):
+        """Run fn() in a helper thread whose HIP work goes to a side stream; returns a join
+        function giving fn's result. The caller's stream must already be synchronised with
+        the data fn reads (estep_finish synchronises)."""
+        import threading
+        torch = self.torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        box = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(self.dev)
+                with torch.cuda.stream(self._side):
+                    box["r"] = fn()
+                    self._side.synchronize()
+            except BaseException as e:  # re-raised by the joiner
+                box["e"] = e
+        th = threading.Thread(target=work)
+        th.start()
+
+        def join():
+            th.join()
+            if "e" in box:
+                raise box["e"]
+            return box["r"]
+        return join
 
     def _set_theta(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)
@@ -190,9 +221,9 @@ class HipBackend:
         resident mean/cov. Returns host arrays f[M], g[M,3] (g None without want_grad)."""
         if self.M == 0:
             return np.zeros(0), (np.zeros((0, 3)) if want_grad else None)
-        stride = self._set_theta(theta)
-        sel, nsel = None, 0
-        if active is not None:
+        theta = np.asarray(theta, dtype=np.float64)
+        sel, nsel, ids = None, 0, None
+        if active is not None and theta.ndim == 2:
             ids = np.nonzero(active)[0].astype(np.int32)
             nsel = int(ids.size)
             if nsel == 0:
@@ -200,13 +231,31 @@ class HipBackend:
             if nsel < self.M:
                 self.sel[:nsel].copy_(self.torch.from_numpy(ids))
                 sel = self.sel
-        self.n_evals += nsel if sel is not None else self.M
+            else:
+                ids = None
+        if sel is not None:  # compact slots: only the running problems cross PCIe
+            self.theta[:3 * nsel].copy_(self.torch.from_numpy(
+                np.ascontiguousarray(theta[ids]).reshape(-1)))
+            stride = 3
+        else:
+            stride = self._set_theta(theta)
+        cnt = nsel if sel is not None else self.M
+        if want_grad:
+            self.n_evals += cnt
         _lib.call("magma_indiv_eval", int(mode), self.M, self.nmax, _ptr(self.off), _ptr(self.t),
                   _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, _ptr(self.mean),
                   _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(sel),
                   nsel, _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
-        f = self.f[:self.M].cpu().numpy()
-        g = self.g[:3 * self.M].cpu().numpy().reshape(self.M, 3) if want_grad else None
+        fc = self.f[:cnt].cpu().numpy()
+        gc = self.g[:3 * cnt].cpu().numpy().reshape(cnt, 3) if want_grad else None
+        if sel is None:
+            return fc, gc
+        f = np.zeros(self.M)
+        f[ids] = fc
+        g = None
+        if want_grad:
+            g = np.zeros((self.M, 3))
+            g[ids] = gc
         return f, g
 
     def theta0_eval(self, theta0, pen_diag, want_grad=True):
@@ -340,8 +389,15 @@ class Engine:
         def ev0(x, act):
             f, g = self.f0(x[0], pen_diag, True)
             return np.array([f]), g[None, :]
-        r0 = minimize_batch(np.asarray(theta0, dtype=np.float64)[None, :], ev0, **kw)
-        new_theta0 = self.comm.bcast_host(r0["x"][0], like=like)
+
+        def run0():
+            return minimize_batch(np.asarray(theta0, dtype=np.float64)[None, :], ev0, **kw)
+        # theta_0 (few dense N x N evaluations, small grids) and the theta_i problems (many
+        # wide launches with host round trips) are independent given the E-step: run theta_0
+        # on a side stream in a helper thread so that the two overlap on the GPU.
+        fut0 = self.be.run_aside(run0) if hasattr(self.be, "run_aside") and not common_hp else None
+        if fut0 is None:
+            r0 = run0()
 
         if common_hp:
             def evc(x, act):
@@ -361,6 +417,9 @@ class Engine:
             else:
                 loc = np.zeros((0, 3))
             new_theta_i = self.comm.allgather_rows(loc, self.counts, like=like)
+        if fut0 is not None:
+            r0 = fut0()
+        new_theta0 = self.comm.bcast_host(r0["x"][0], like=like)
         return new_theta0, new_theta_i
 
     # ------------------------------------------------------------ EM driver (MG:15-82)
