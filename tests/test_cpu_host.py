@@ -1,0 +1,111 @@
+"""CPU-only tests: the C ABI library loads and exports what include/magma_hip.h declares, the
+host-side L-BFGS-B restatement against scipy's, the Dataset layout, and the oracle's own
+consistency checks (finite differences, E-step == posterior_mu identity, n = 1)."""
+import os
+import re
+import ctypes
+import numpy as np
+import pytest
+
+from oracle import magma_oracle as orc
+from kat_common import dataset, hp_of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from magma_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "magma_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(magma_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
+    assert _lib.load().magma_pad(2000) == 2048 and _lib.load().magma_pad(64) == 64
+
+
+def test_lbfgsb_matches_scipy_on_rosenbrock_batch():
+    from scipy.optimize import minimize, rosen, rosen_der
+    from magma_amd.lbfgsb import minimize_batch
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-2, 2, size=(8, 3))
+
+    def ev(x, act):
+        return np.array([rosen(v) for v in x]), np.array([rosen_der(v) for v in x])
+    res = minimize_batch(x0, ev, maxit=100)
+    for b in range(8):
+        r = minimize(rosen, x0[b], jac=rosen_der, method="L-BFGS-B",
+                     options={"maxcor": 5, "ftol": 1e7 * np.finfo(float).eps, "gtol": 0.0,
+                              "maxiter": 100, "maxls": 20})
+        assert res["nfev"][b] == r.nfev and res["iters"][b] == r.nit, (b, res["nfev"][b], r.nfev)
+        assert np.abs(res["x"][b] - r.x).max() < 1e-6
+    assert np.all(res["status"] == 1)
+
+
+def test_lbfgsb_recovers_from_non_finite_trial_points():
+    from magma_amd.lbfgsb import minimize_batch
+
+    calls = {"nan": 0}
+
+    def ev(x, act):  # flat quadratic with its minimum next to a wall of NaN at x >= 3
+        bad = x[:, 0] >= 3.0
+        calls["nan"] += int(bad.sum())
+        f = np.where(bad, np.nan, 1e-4 * ((x - 2.9) ** 2).sum(axis=1))
+        return f, np.where(bad[:, None], np.nan, 2e-4 * (x - 2.9))
+    res = minimize_batch(np.array([[2.5, 2.5], [1.0, 2.0]]), ev)
+    assert calls["nan"] > 0  # the first (unit-length) trial step lands behind the wall
+    assert np.all(np.isin(res["status"], (1, 2))) and np.abs(res["x"] - 2.9).max() < 1e-3
+    res = minimize_batch(np.array([[5.0, 0.0]]), ev)  # cannot even start: R errors, we flag
+    assert res["status"][0] == 5 and np.all(np.isnan(res["x"]))
+
+
+# ----------------------------------------------------------------- oracle self-consistency
+def _fd(fn, x, h=1e-6):
+    g = np.zeros_like(x)
+    for k in range(x.size):
+        e = np.zeros_like(x)
+        e[k] = h
+        g[k] = (fn(x + e) - fn(x - e)) / (2 * h)
+    return g
+
+
+@pytest.mark.parametrize("n", [1, 2, 12])
+def test_oracle_gradients_match_finite_differences(n):
+    rng = np.random.default_rng(n)
+    t = np.sort(rng.choice(np.arange(0, 10, 0.05), n, replace=False))
+    db = {"Timestamp": t, "Output": rng.normal(size=n)}
+    B = rng.normal(size=(n, n))
+    C = B @ B.T / n
+    mean = rng.normal(size=n)
+    hp = np.array([0.7, 0.3, 0.6])
+    for fn, gr in ((orc.logL_GP_mod, orc.gr_GP_mod), (orc.logL_GP, orc.gr_GP)):
+        g = gr(hp, db, mean, orc.kernel, C)
+        g_fd = _fd(lambda p: fn(p, db, mean, orc.kernel, C), hp)
+        assert np.abs(g - g_fd).max() < 1e-5 * max(1.0, np.abs(g).max())
+    g = orc.gr_GP_mod(hp[:2], db, mean, orc.kernel, C, pen_diag=0.5)
+    g_fd = _fd(lambda p: orc.logL_GP_mod(p, db, mean, orc.kernel, C, pen_diag=0.5), hp[:2])
+    assert np.abs(g - g_fd).max() < 1e-5 * max(1.0, np.abs(g).max())
+
+
+def test_oracle_estep_equals_posterior_mu_on_training_grid():
+    _, test, train = dataset("data_FF", 2)
+    hp = hp_of("hp_FF", 2)
+    e = orc.e_step(train, 0.0, orc.kernel, orc.kernel, hp)
+    empty = {"ID": np.zeros(0), "Timestamp": np.zeros(0), "Output": np.zeros(0)}
+    p = orc.posterior_mu(train, empty, np.zeros(0), 0.0, orc.kernel, orc.kernel, hp, "mean_sigma")
+    assert np.array_equal(e["mean"]["Timestamp"], p["mean"]["Timestamp"])
+    assert np.abs(e["cov"][1] - p["cov"][1]).max() == 0.0
+
+
+@pytest.mark.parametrize("d", [1, 4])
+def test_oracle_training_reproduces_stored_hyperparameters(d):
+    """Full EM (`training`, MAGMA.R:15-82) with scipy's L-BFGS-B against the HPs R stored in
+    train_FT.rds: pins e_step / m_step / logL_* / gr_* / the stopping rule of the oracle."""
+    _, _, train = dataset("data_FT", d)
+    res = orc.training(train, 0.0, {"theta_0": [1.0, 1.0], "theta_i": [1.0, 1.0, 0.2]},
+                       orc.kernel, orc.kernel, common_hp=True)
+    ref = hp_of("hp_FT", d)
+    assert np.abs(res["hp"]["theta_0"] - ref["theta_0"]).max() < 1e-8
+    assert max(np.abs(res["hp"]["theta_i"][i] - v).max() for i, v in ref["theta_i"].items()) < 1e-8
