@@ -1,0 +1,221 @@
+/* R `.Call` shim over the C ABI of libmagma_hip.so (include/magma_hip.h).
+ *
+ * NOT compiled or tested in this repository's CI: the build image has no R (no Rinternals.h).
+ * Build where R exists:   R CMD SHLIB r_shim.c -L../magma_amd -lmagma_hip -o magmahip.so
+ * and load it from the sourced scripts with dyn.load("magmahip.so") (the reference is
+ * script based: MAGMA.R:12 sources Computing_functions.R).
+ *
+ * Conventions: inputs are read-only REAL()/INTEGER() views; outputs are freshly allocated,
+ * column-major; a "session" external pointer owns the device copy of one db (ragged layout +
+ * union grid + dense workspace) and is released by a finalizer. C ABI status codes become
+ * Rf_error() AFTER all C resources of the call are released (no longjmp over live state).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/magma_hip.h"
+
+typedef struct {
+  int M, N, Np, nmax;
+  int64_t *off;          /* device */
+  double *t, *y, *grid;  /* device */
+  int *idx;              /* device */
+  double *theta, *f, *g, *P, *w, *mean, *m0;
+  int *info;
+  void *work;
+} session;
+
+static void sess_free(session *s) {
+  if (!s) return;
+  void *p[] = {s->off, s->t, s->y, s->grid, s->idx, s->theta, s->f, s->g, s->P, s->w,
+               s->mean, s->m0, s->info, s->work};
+  for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i)
+    if (p[i]) magma_dev_free(p[i]);
+  free(s);
+}
+
+static void sess_finalizer(SEXP x) {
+  sess_free((session *)R_ExternalPtrAddr(x));
+  R_ClearExternalPtr(x);
+}
+
+static session *get_sess(SEXP x) {
+  session *s = (session *)R_ExternalPtrAddr(x);
+  if (!s) Rf_error("magmahip: session already released");
+  return s;
+}
+
+static int up(void **dst, const void *src, size_t bytes) {
+  int rc = magma_dev_malloc(dst, bytes ? bytes : 8);
+  if (rc == 0 && bytes) rc = magma_memcpy_h2d(*dst, src, bytes, NULL);
+  return rc;
+}
+
+/* off: integer M+1 (0-based row offsets), t/y: double, idx: integer (0-based), grid: double N */
+SEXP magmahip_session(SEXP off, SEXP t, SEXP y, SEXP idx, SEXP grid) {
+  session *s = (session *)calloc(1, sizeof(session));
+  if (!s) Rf_error("magmahip: out of memory");
+  s->M = LENGTH(off) - 1;
+  s->N = LENGTH(grid);
+  s->Np = magma_pad(s->N);
+  const int tot = LENGTH(t);
+  int64_t *off64 = (int64_t *)malloc(sizeof(int64_t) * (s->M + 1));
+  double *gridp = (double *)calloc(s->Np, sizeof(double));
+  int rc = (off64 && gridp) ? 0 : 1;
+  if (rc == 0) {
+    s->nmax = 1;
+    for (int i = 0; i <= s->M; ++i) off64[i] = INTEGER(off)[i];
+    for (int i = 0; i < s->M; ++i)
+      if (off64[i + 1] - off64[i] > s->nmax) s->nmax = (int)(off64[i + 1] - off64[i]);
+    memcpy(gridp, REAL(grid), sizeof(double) * s->N);
+    const size_t n2 = (size_t)s->Np * s->Np, Mb = s->M > 0 ? s->M : 1;
+    rc = up((void **)&s->off, off64, sizeof(int64_t) * (s->M + 1));
+    if (!rc) rc = up((void **)&s->t, REAL(t), sizeof(double) * tot);
+    if (!rc) rc = up((void **)&s->y, REAL(y), sizeof(double) * tot);
+    if (!rc) rc = up((void **)&s->idx, INTEGER(idx), sizeof(int) * tot);
+    if (!rc) rc = up((void **)&s->grid, gridp, sizeof(double) * s->Np);
+    if (!rc) rc = magma_dev_malloc((void **)&s->theta, sizeof(double) * 3 * Mb);
+    if (!rc) rc = magma_dev_malloc((void **)&s->f, sizeof(double) * Mb);
+    if (!rc) rc = magma_dev_malloc((void **)&s->g, sizeof(double) * 3 * Mb);
+    if (!rc) rc = magma_dev_malloc((void **)&s->info, sizeof(int) * Mb);
+    if (!rc) rc = magma_dev_malloc((void **)&s->P, sizeof(double) * n2);
+    if (!rc) rc = magma_dev_malloc((void **)&s->w, sizeof(double) * s->Np);
+    if (!rc) rc = magma_dev_malloc((void **)&s->mean, sizeof(double) * s->Np);
+    if (!rc) rc = magma_dev_malloc((void **)&s->m0, sizeof(double) * s->Np);
+    if (!rc) rc = magma_dev_malloc(&s->work, magma_workspace_bytes(s->N));
+    if (!rc) rc = magma_stream_sync(NULL);
+  }
+  free(off64);
+  free(gridp);
+  if (rc) {
+    sess_free(s);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP ptr = PROTECT(R_MakeExternalPtr(s, R_NilValue, R_NilValue));
+  R_RegisterCFinalizerEx(ptr, sess_finalizer, TRUE);
+  UNPROTECT(1);
+  return ptr;
+}
+
+static int put_vec_padded(session *s, double *dst, SEXP v) {
+  double *tmp = (double *)calloc(s->Np, sizeof(double));
+  if (!tmp) return 1;
+  const int n = LENGTH(v);
+  for (int i = 0; i < s->N; ++i) tmp[i] = REAL(v)[n == 1 ? 0 : i];
+  int rc = magma_memcpy_h2d(dst, tmp, sizeof(double) * s->Np, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  free(tmp);
+  return rc;
+}
+
+/* e_step / posterior_mu body (CF:371-395, MG:107-133). theta_i: 3 x M matrix or length 3. */
+SEXP magmahip_e_step(SEXP sx, SEXP theta0, SEXP pen, SEXP theta_i, SEXP m0) {
+  session *s = get_sess(sx);
+  const int stride = LENGTH(theta_i) == 3 ? 0 : 3;
+  const size_t n2 = (size_t)s->Np * s->Np;
+  int hinfo = 0;
+  int rc = magma_memcpy_h2d(s->theta, REAL(theta_i), sizeof(double) * LENGTH(theta_i), NULL);
+  if (!rc) rc = put_vec_padded(s, s->m0, m0);
+  if (!rc) rc = magma_memset_zero(s->P, sizeof(double) * n2, NULL);
+  if (!rc) rc = magma_memset_zero(s->w, sizeof(double) * s->Np, NULL);
+  if (!rc) rc = magma_estep_scatter(s->M, s->nmax, s->off, s->t, s->y, s->idx, s->theta, stride,
+                                    s->N, s->P, s->w, s->info, NULL);
+  if (!rc) rc = magma_estep_finish(s->N, s->grid, REAL(theta0)[0], REAL(theta0)[1], REAL(pen)[0],
+                                   s->m0, s->P, s->w, s->mean, s->work, &hinfo, NULL);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  SEXP mean = PROTECT(allocVector(REALSXP, s->N));
+  SEXP cov = PROTECT(allocMatrix(REALSXP, s->N, s->N));
+  double *tmp = NULL;
+  rc = magma_dev_malloc((void **)&tmp, sizeof(double) * (size_t)s->N * s->N);
+  if (!rc) rc = magma_copy_unpad(s->N, s->P, tmp, s->N, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(cov), tmp, sizeof(double) * (size_t)s->N * s->N, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(mean), s->mean, sizeof(double) * s->N, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  if (tmp) magma_dev_free(tmp);
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, mean);
+  SET_VECTOR_ELT(out, 1, cov);
+  SET_VECTOR_ELT(out, 2, ScalarInteger(hinfo)); /* != 0: fall back to solve()/ginv() in R */
+  UNPROTECT(3);
+  return out;
+}
+
+/* Load a hyper-posterior computed elsewhere (mean: N, cov: N x N on the session's grid). */
+SEXP magmahip_set_posterior(SEXP sx, SEXP mean, SEXP cov) {
+  session *s = get_sess(sx);
+  double *tmp = NULL;
+  int rc = put_vec_padded(s, s->mean, mean);
+  if (!rc) rc = up((void **)&tmp, REAL(cov), sizeof(double) * (size_t)s->N * s->N);
+  if (!rc) rc = magma_copy_pad(s->N, tmp, s->N, s->P, 0, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  if (tmp) magma_dev_free(tmp);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  return R_NilValue;
+}
+
+/* logL_GP_mod / gr_GP_mod (mode 0) or logL_GP / gr_GP (mode 1) for every individual. */
+SEXP magmahip_indiv_eval(SEXP sx, SEXP theta_i, SEXP want_grad, SEXP mode) {
+  session *s = get_sess(sx);
+  const int stride = LENGTH(theta_i) == 3 ? 0 : 3, wg = asLogical(want_grad);
+  int rc = magma_memcpy_h2d(s->theta, REAL(theta_i), sizeof(double) * LENGTH(theta_i), NULL);
+  if (!rc) rc = magma_indiv_eval(asInteger(mode), s->M, s->nmax, s->off, s->t, s->y, s->idx,
+                                 s->theta, stride, s->mean, s->P, s->N, wg, NULL, 0, s->f, s->g,
+                                 s->info, NULL);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  SEXP f = PROTECT(allocVector(REALSXP, s->M));
+  SEXP g = PROTECT(allocMatrix(REALSXP, 3, s->M));
+  SEXP info = PROTECT(allocVector(INTSXP, s->M));
+  rc = magma_memcpy_d2h(REAL(f), s->f, sizeof(double) * s->M, NULL);
+  if (!rc && wg) rc = magma_memcpy_d2h(REAL(g), s->g, sizeof(double) * 3 * s->M, NULL);
+  if (!rc) rc = magma_memcpy_d2h(INTEGER(info), s->info, sizeof(int) * s->M, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  if (rc) {
+    UNPROTECT(3);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, f);
+  SET_VECTOR_ELT(out, 1, g);
+  SET_VECTOR_ELT(out, 2, info);
+  UNPROTECT(4);
+  return out;
+}
+
+/* logL_GP_mod + gr_GP_mod at theta_0: returns c(f, g1, g2, info). */
+SEXP magmahip_theta0_eval(SEXP sx, SEXP theta0, SEXP pen, SEXP m0, SEXP want_grad) {
+  session *s = get_sess(sx);
+  double out3[3] = {0, 0, 0};
+  int hinfo = 0;
+  int rc = put_vec_padded(s, s->m0, m0);
+  if (!rc) rc = magma_theta0_eval(s->N, s->grid, REAL(theta0)[0], REAL(theta0)[1], REAL(pen)[0],
+                                  s->mean, s->m0, s->P, asLogical(want_grad), s->work, out3,
+                                  &hinfo, NULL);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  SEXP out = PROTECT(allocVector(REALSXP, 4));
+  REAL(out)[0] = out3[0];
+  REAL(out)[1] = out3[1];
+  REAL(out)[2] = out3[2];
+  REAL(out)[3] = (double)hinfo;
+  UNPROTECT(1);
+  return out;
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"magmahip_session", (DL_FUNC)&magmahip_session, 5},
+    {"magmahip_e_step", (DL_FUNC)&magmahip_e_step, 5},
+    {"magmahip_set_posterior", (DL_FUNC)&magmahip_set_posterior, 3},
+    {"magmahip_indiv_eval", (DL_FUNC)&magmahip_indiv_eval, 4},
+    {"magmahip_theta0_eval", (DL_FUNC)&magmahip_theta0_eval, 5},
+    {NULL, NULL, 0}};
+
+void R_init_magmahip(DllInfo *dll) {
+  R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
