@@ -84,10 +84,15 @@ int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, co
 /* Rest of e_step (CF:382,386-391) / posterior_mu (MG:118-128): K_0^-1 on the grid with
  * `pen_diag` on the diagonal, P += K_0^-1, w += K_0^-1 m_0, cov = P^-1 (blocked MFMA Cholesky,
  * in place in P, full symmetric), mean = cov w. m0: Np values. h_info: host int, LAPACK-style
- * status of the two factorisations (0 ok; synchronises the stream). */
+ * status of the two factorisations (0 ok; synchronises the stream).
+ * reuse_k0inv != 0: the workspace still holds K_0^-1 for exactly (theta1, theta2, pen_diag)
+ * from the caller's last f-only magma_theta0_eval on it (what logL_monitoring of the accepted
+ * hyper-parameters computed, CF:251-252), so it is not rebuilt.
+ * h_f0 (optional, host): logL_GP_mod(theta_0) at the NEW hyper-posterior with this pen_diag,
+ * i.e. the theta_0 term of the following logL_monitoring (CF:252), from the same K_0^-1. */
 int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
                        const double* m0, double* P, double* w, double* mean_out, void* work,
-                       int* h_info, void* stream);
+                       int reuse_k0inv, double* h_f0, int* h_info, void* stream);
 /* Dense SPD inverse + log-det on its own (solve(), determinant(): CF:27,133,387). A: in =
  * SPD matrix (lower triangle read), out = full symmetric inverse. d_logdet, d_info: device. */
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream);

@@ -165,18 +165,18 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
 
 int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
                        const double* m0, double* P, double* w, double* mean_out, void* work,
-                       int* h_info, void* stream) {
+                       int reuse_k0inv, double* h_f0, int* h_info, void* stream) {
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = magma_pad(N);
   const size_t n2 = (size_t)Np * Np;
   hipStream_t st = S(stream);
   Work wk(work, Np);
   int rc;
-  {
-    Prof pf(PROF_COV_GRID, st);
-    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
-  }
-  {
+  if (!reuse_k0inv) {
+    {
+      Prof pf(PROF_COV_GRID, st);
+      if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+    }
     Prof pf(PROF_SPD_INVERSE, st);
     if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
   }
@@ -188,6 +188,18 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
     if ((rc = launch_spd_inverse(Np, P, wk.scal + 5, wk.iinfo + 1, wk.inv, st))) return rc;
   }
   if ((rc = launch_symv(Np, P, w, mean_out, st))) return rc;
+  if (h_f0) {
+    // logL_GP_mod(theta_0; db = new mean, new_cov = new cov, pen_diag) from the K_0^-1 that is
+    // still in the workspace: z'K_0^-1 z, log|K_0| and sum(K_0^-1 o cov) -- no factorisation.
+    MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, mean_out, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
+    if ((rc = launch_axpy(Np, -1.0, m0, wk.z, st))) return rc;
+    if (Np > N) MAGMA_CHECK_HIP(hipMemsetAsync(wk.z + N, 0, sizeof(double) * (Np - N), st));
+    if ((rc = launch_symv(Np, wk.A0, wk.z, wk.alpha, st))) return rc;
+    if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
+    if ((rc = launch_dot((int64_t)n2, wk.A0, P, wk.partials, wk.scal + 2, st))) return rc;
+    if ((rc = launch_theta0_finish(N, Np, wk.scal, wk.scal + 8, 0, st))) return rc;
+    MAGMA_CHECK_HIP(hipMemcpyAsync(h_f0, wk.scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   int hinfo[2] = {0, 0};
   MAGMA_CHECK_HIP(hipMemcpyAsync(hinfo, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   MAGMA_CHECK_HIP(hipStreamSynchronize(st));

@@ -130,6 +130,10 @@ class HipBackend:
         self.cov = self.P  # alias: after estep_finish P holds the covariance
         self.n_evals = 0  # individual objective evaluations launched (for roofline figures)
         self._side = None
+        self._a0_key = None  # (theta1, theta2, pen) whose K_0^-1 sits in the workspace
+        pin = lambda n, dt: torch.empty(n, dtype=dt).pin_memory()  # noqa: E731
+        self.h_theta, self.h_sel = pin(Mb * 3, f64), pin(Mb, torch.int32)
+        self.h_f, self.h_g = pin(Mb, f64), pin(Mb * 3, f64)
 
     # -- plumbing
     def stream(self):
@@ -208,12 +212,18 @@ class HipBackend:
             return 0
         return int((self.info[:self.M] != 0).sum().item())
 
-    def estep_finish(self, theta0, pen_diag):
+    def estep_finish(self, theta0, pen_diag, want_f0=False):
+        """Returns (info, f0): f0 = logL_GP_mod(theta_0) at the new hyper-posterior with this
+        pen_diag (the theta_0 term of the next logL_monitoring), or None."""
         info = C.c_int(0)
-        _lib.call("magma_estep_finish", self.N, _ptr(self.grid), float(theta0[0]),
-                  float(theta0[1]), float(pen_diag), _ptr(self.m0), _ptr(self.P), _ptr(self.w),
-                  _ptr(self.mean), _ptr(self.work), C.byref(info), self.stream())
-        return info.value
+        f0 = C.c_double(0.0)
+        key = (float(theta0[0]), float(theta0[1]), float(pen_diag))
+        reuse = int(self._a0_key == key)  # K_0^-1 left by the last f-only theta_0 evaluation
+        _lib.call("magma_estep_finish", self.N, _ptr(self.grid), key[0], key[1], key[2],
+                  _ptr(self.m0), _ptr(self.P), _ptr(self.w), _ptr(self.mean), _ptr(self.work),
+                  reuse, C.byref(f0) if want_f0 else None, C.byref(info), self.stream())
+        self._a0_key = key if info.value == 0 else None
+        return info.value, (f0.value if want_f0 else None)
 
     # -- M-step objective / gradient
     def indiv_eval(self, theta, want_grad=True, mode=0, active=None, use_cov=True):
@@ -229,25 +239,32 @@ class HipBackend:
             if nsel == 0:
                 return np.zeros(self.M), (np.zeros((self.M, 3)) if want_grad else None)
             if nsel < self.M:
-                self.sel[:nsel].copy_(self.torch.from_numpy(ids))
+                self.h_sel[:nsel].numpy()[:] = ids
+                self.sel[:nsel].copy_(self.h_sel[:nsel], non_blocking=True)
                 sel = self.sel
             else:
                 ids = None
-        if sel is not None:  # compact slots: only the running problems cross PCIe
-            self.theta[:3 * nsel].copy_(self.torch.from_numpy(
-                np.ascontiguousarray(theta[ids]).reshape(-1)))
-            stride = 3
-        else:
-            stride = self._set_theta(theta)
+        torch = self.torch
         cnt = nsel if sel is not None else self.M
+        if theta.ndim == 1:
+            stride = self._set_theta(theta)
+        else:  # one pinned staging copy per array, all asynchronous on the launch stream
+            rows = theta[ids] if sel is not None else theta
+            self.h_theta[:3 * cnt].numpy()[:] = np.ascontiguousarray(rows).reshape(-1)
+            self.theta[:3 * cnt].copy_(self.h_theta[:3 * cnt], non_blocking=True)
+            stride = 3
         if want_grad:
             self.n_evals += cnt
         _lib.call("magma_indiv_eval", int(mode), self.M, self.nmax, _ptr(self.off), _ptr(self.t),
                   _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, _ptr(self.mean),
                   _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(sel),
                   nsel, _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
-        fc = self.f[:cnt].cpu().numpy()
-        gc = self.g[:3 * cnt].cpu().numpy().reshape(cnt, 3) if want_grad else None
+        self.h_f[:cnt].copy_(self.f[:cnt], non_blocking=True)
+        if want_grad:
+            self.h_g[:3 * cnt].copy_(self.g[:3 * cnt], non_blocking=True)
+        torch.cuda.current_stream(self.dev).synchronize()
+        fc = self.h_f[:cnt].numpy().copy()
+        gc = self.h_g[:3 * cnt].numpy().reshape(cnt, 3).copy() if want_grad else None
         if sel is None:
             return fc, gc
         f = np.zeros(self.M)
@@ -265,6 +282,8 @@ class HipBackend:
                   float(theta0[1]), float(pen_diag), _ptr(self.mean), _ptr(self.m0),
                   _ptr(self.cov), int(bool(want_grad)), _ptr(self.work), out, C.byref(info),
                   self.stream())
+        self._a0_key = ((float(theta0[0]), float(theta0[1]), float(pen_diag))
+                        if info.value == 0 else None)
         f = out[0] if info.value == 0 else float("nan")
         return f, np.array([out[1], out[2]]), info.value
 
@@ -351,7 +370,7 @@ class Engine:
         self.comm.allreduce_(P)
         self.comm.allreduce_(w)
         self.stats["flagged"] += be.n_flagged()
-        info = be.estep_finish(theta0, pen_diag)
+        info, self.last_f0 = be.estep_finish(theta0, pen_diag, want_f0=True)
         return info
 
     # ------------------------------------------------------------ objectives
@@ -405,6 +424,7 @@ class Engine:
                 f, g = self.sum_fi(x[0], True)
                 return np.array([f]), g[None, :]
             rc = minimize_batch(theta_i[0][None, :], evc, **kw)
+            self.last_sum_fi = float(rc["f_x0"][0])  # already summed over ranks
             par = self.comm.bcast_host(rc["x"][0], like=like)
             new_theta_i = np.tile(par, (theta_i.shape[0], 1))
         else:
@@ -413,9 +433,10 @@ class Engine:
                 return self.be.indiv_eval(x, True, active=act)
             if self.hi > self.lo:
                 ri = minimize_batch(theta_i[self.lo:self.hi], evi, **kw)
-                loc = ri["x"]
+                loc, fsum = ri["x"], float(np.sum(ri["f_x0"]))
             else:
-                loc = np.zeros((0, 3))
+                loc, fsum = np.zeros((0, 3)), 0.0
+            self.last_sum_fi = float(self.comm.allreduce_host(np.array([fsum]), like=like)[0])
             new_theta_i = self.comm.allgather_rows(loc, self.counts, like=like)
         if fut0 is not None:
             r0 = fut0()
@@ -432,7 +453,10 @@ class Engine:
         new_theta0, new_theta_i = self.m_step(theta0, theta_i, common_hp, opt_kw)
         if np.any(np.isnan(new_theta0)) or np.any(np.isnan(new_theta_i)):
             return new_theta0, new_theta_i, np.nan, np.nan
-        l_old = self.logL_monitoring(theta0, theta_i)
+        # logL_monitoring(hp) (MG:54) costs nothing extra: its theta_0 term came out of the
+        # E-step's K_0^-1 (same theta_0, same pen_diag = mean sigma_i: CF:251, 381) and its
+        # individual terms are the optimisers' first evaluations at the old theta_i.
+        l_old = -self.last_f0 - self.last_sum_fi
         l_new = self.logL_monitoring(new_theta0, new_theta_i)
         return new_theta0, new_theta_i, l_old, l_new
 

@@ -27,6 +27,7 @@ def minimize_batch(x0, evaluate, m=5, factr=1e7, pgtol=0.0, maxit=100, max_round
         active = np.empty(B, dtype=np.uint8)
         nact = C.c_int(0)
         rounds = 0
+        f_first = None
         while True:
             _lib.check(lib.magma_lbfgsb_ask(h, x.ctypes.data, active.ctypes.data, C.byref(nact)))
             if nact.value == 0 or rounds >= max_rounds:
@@ -34,6 +35,8 @@ def minimize_batch(x0, evaluate, m=5, factr=1e7, pgtol=0.0, maxit=100, max_round
             f, g = evaluate(x, active.astype(bool))
             f = np.ascontiguousarray(f, dtype=np.float64)
             g = np.ascontiguousarray(g, dtype=np.float64)
+            if f_first is None:
+                f_first = f.copy()  # objective at x0 (every problem is active in round 1)
             _lib.check(lib.magma_lbfgsb_tell(h, f.ctypes.data, g.ctypes.data))
             rounds += 1
         xr = np.empty((B, d))
@@ -45,4 +48,5 @@ def minimize_batch(x0, evaluate, m=5, factr=1e7, pgtol=0.0, maxit=100, max_round
                                            nf.ctypes.data, stt.ctypes.data))
     finally:
         lib.magma_lbfgsb_destroy(h)
-    return {"x": xr, "f": fr, "iters": it, "nfev": nf, "status": stt, "rounds": rounds}
+    return {"x": xr, "f": fr, "iters": it, "nfev": nf, "status": stt, "rounds": rounds,
+            "f_x0": f_first}

@@ -124,7 +124,7 @@ SEXP magmahip_e_step(SEXP sx, SEXP theta0, SEXP pen, SEXP theta_i, SEXP m0) {
   if (!rc) rc = magma_estep_scatter(s->M, s->nmax, s->off, s->t, s->y, s->idx, s->theta, stride,
                                     s->N, s->P, s->w, s->info, NULL);
   if (!rc) rc = magma_estep_finish(s->N, s->grid, REAL(theta0)[0], REAL(theta0)[1], REAL(pen)[0],
-                                   s->m0, s->P, s->w, s->mean, s->work, &hinfo, NULL);
+                                   s->m0, s->P, s->w, s->mean, s->work, 0, NULL, &hinfo, NULL);
   if (rc) Rf_error("magmahip: %s", magma_last_error());
   SEXP mean = PROTECT(allocVector(REALSXP, s->N));
   SEXP cov = PROTECT(allocMatrix(REALSXP, s->N, s->N));

@@ -49,13 +49,14 @@ class OracleBackend:
     def n_flagged(self):
         return 0
 
-    def estep_finish(self, theta0, pen_diag):
+    def estep_finish(self, theta0, pen_diag, want_f0=False):
         _, inv0 = orc.kern_to_inv(self.grid, orc.kernel, theta0, pen_diag)
         P = self.P.numpy().reshape(self.N, self.N) + inv0
         w = self.w.numpy() + inv0 @ self.m0
         self.cov = np.linalg.inv(P)
         self.mean = self.cov @ w
-        return 0
+        f0 = self.theta0_eval(theta0, pen_diag, False)[0] if want_f0 else None
+        return 0, f0
 
     def indiv_eval(self, theta, want_grad=True, mode=0, active=None, use_cov=True):
         f = np.zeros(self.M)

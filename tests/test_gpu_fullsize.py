@@ -52,7 +52,7 @@ def test_c3_estep_round_trip_and_shard_additivity(gpu):
     assert np.abs(acc_w - w_full).max() < 1e-11 * np.abs(w_full).max()
     # finish: cov must invert (K0^-1 + scatter), mean = cov (K0^-1 m0 + w)
     be.set_m0(m0)
-    assert be.estep_finish(th0, pen) == 0
+    assert be.estep_finish(th0, pen)[0] == 0
     cov, mean = be.get_cov(), be.get_mean()
     K0inv = np.linalg.inv(orc.kern_to_cov(ds.grid, orc.kernel, th0, pen)[1])
     prec = P_full + K0inv

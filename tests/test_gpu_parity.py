@@ -258,3 +258,35 @@ def test_pred_gp_matches_oracle(gpu):
     exp = orc.pred_gp(db_obs, None, 2.0, None, orc.kernel, [1.1, 0.6], 0.3)
     assert np.abs(got["Mean"] - exp["Mean"]).max() < 1e-9 * np.abs(exp["Mean"]).max()
     assert np.abs(got["Var"] - exp["Var"]).max() < 1e-9 * np.abs(exp["Var"]).max()
+
+
+def test_em_iteration_shortcuts_equal_explicit_monitoring(gpu):
+    """The engine takes logL_monitoring(hp) from by-products (K_0^-1 of the E-step, the
+    optimisers' first evaluations) and reuses K_0^-1 between monitoring(new hp) and the next
+    E-step: both must equal the explicit computations and the oracle."""
+    from magma_amd.engine import Dataset, Engine
+    rng = np.random.default_rng(21)
+    db = _ragged_db(rng, [30, 12, 40, 7, 25, 33])
+    ds = Dataset(db)
+    eng = Engine(ds)
+    th0 = np.array([1.0, 1.0])
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+    for common in (False, True):
+        n0, ni, l_old, l_new = eng.em_iteration(th0, thi, 0.4, common)
+        hp = {"theta_0": th0, "theta_i": {i: thi[k] for k, i in enumerate(ds.ids)}}
+        par = orc.e_step(db, 0.4, orc.kernel, orc.kernel, hp)
+        ll = orc.logL_monitoring(hp, db, orc.kernel, orc.kernel, par["mean"], par["cov"], 0.4)
+        assert abs(l_old - ll) < 1e-9 * abs(ll), (common, l_old, ll)
+        assert abs(eng.logL_monitoring(th0, thi) - ll) < 1e-9 * abs(ll)
+        hp_n = {"theta_0": n0, "theta_i": {i: ni[k] for k, i in enumerate(ds.ids)}}
+        ll_n = orc.logL_monitoring(hp_n, db, orc.kernel, orc.kernel, par["mean"], par["cov"], 0.4)
+        assert abs(l_new - ll_n) < 1e-9 * abs(ll_n)
+        # next E-step right after monitoring(new hp): K_0^-1 reuse path vs a cold engine
+        eng.logL_monitoring(n0, ni)
+        eng.e_step(n0, ni, float(np.mean(ni[:, 2])), 0.4)
+        cold = Engine(ds)
+        cold.e_step(n0, ni, float(np.mean(ni[:, 2])), 0.4)
+        # (not bitwise: the scatter's FP64 atomics commit in a run-dependent order)
+        c1, c2 = eng.be.get_cov(), cold.be.get_cov()
+        assert np.abs(c1 - c2).max() < 1e-12 * np.abs(c2).max()
+        assert abs(eng.last_f0 - cold.last_f0) <= 1e-11 * abs(cold.last_f0)
