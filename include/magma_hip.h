@@ -104,13 +104,22 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
  * info_out[M]. sel (optional): nsel int32 indices of the individuals to evaluate (a lock-step
  * optimiser passes the problems still running); then theta, f_out, g_out and info_out are
  * COMPACT: slot b belongs to individual sel[b]. NULL = all M, slot = individual.
- * cov may be NULL (C = 0).
+ * cpack: the individuals' blocks C_i = cov[idx_i, idx_i] packed by magma_indiv_gather_cov
+ * (the hyper-posterior is fixed during an M-step, so the gather is done once and every
+ * evaluation streams contiguous data); NULL = C is zero.
  * The common-HP objective (CF:203-234, 334-368) is the sum of these over individuals with
  * theta_stride = 0. */
 int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
                      const double* y, const int* idx, const double* theta, int theta_stride,
-                     const double* mean, const double* cov, int N, int want_grad, const int* sel,
+                     const double* mean, const double* cpack, int want_grad, const int* sel,
                      int nsel, double* f_out, double* g_out, int* info_out, void* stream);
+/* new_cov[idx_i, idx_i] of CF:188,312 (`cov[paste0('X', t_i), paste0('X', t_i)]`) for all M
+ * individuals at once, cov = the padded N x N matrix left by magma_estep_finish. cpack (device):
+ * M * magma_cpack_stride(nmax) doubles; slot i is C_i column-major, zero padded to the tile
+ * shape the evaluation kernel for this nmax loads (opaque to the caller). */
+int64_t magma_cpack_stride(int nmax);
+int magma_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
+                           const double* cov, int N, double* cpack, void* stream);
 /* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
  * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
  * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */

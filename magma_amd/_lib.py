@@ -38,8 +38,10 @@ SIGNATURES = {
     "magma_estep_finish": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _p, _p, _i, C.POINTER(_d),
                                 C.POINTER(_i), _p]),
     "magma_spd_inverse": (_i, [_i, _p, _p, _p, _p, _p]),
-    "magma_indiv_eval": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p,
+    "magma_indiv_eval": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p,
                               _p, _p, _p]),
+    "magma_cpack_stride": (_i64, [_i]),
+    "magma_indiv_gather_cov": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "magma_theta0_eval": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _i, _p, C.POINTER(_d),
                                C.POINTER(_i), _p]),
     "magma_sum": (_i, [_i64, _p, _p, C.POINTER(_d), _p]),

@@ -56,7 +56,8 @@ static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 // Optional per-kernel-class timing with HIP events on the launching stream (bench.py's
 // roofline figures): off by default, no cost when off.
 enum ProfId { PROF_GEMM = 0, PROF_CONTRACT, PROF_SPD_INVERSE, PROF_INDIV_EVAL, PROF_INDIV_F,
-              PROF_SCATTER, PROF_COV_GRID, PROF_COV_BATCHED, PROF_INV_BATCHED, PROF_N };
+              PROF_SCATTER, PROF_COV_GRID, PROF_COV_BATCHED, PROF_INV_BATCHED, PROF_GATHER_COV,
+              PROF_N };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_N];
@@ -209,7 +210,7 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
 
 int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
                      const double* y, const int* idx, const double* theta, int theta_stride,
-                     const double* mean, const double* cov, int N, int want_grad, const int* sel,
+                     const double* mean, const double* cpack, int want_grad, const int* sel,
                      int nsel, double* f_out, double* g_out, int* info_out, void* stream) {
   if (int rc = check_small(M, nmax)) return rc;
   if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
@@ -217,8 +218,21 @@ int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double
   if (sel != nullptr && (nsel < 0 || nsel > M)) return fail(2, "nsel must be in 0..M");
   const int count = sel ? nsel : M;
   Prof pf(want_grad ? PROF_INDIV_EVAL : PROF_INDIV_F, S(stream));
-  return launch_indiv_eval(count, sel, nmax, off, t, y, idx, theta, theta_stride, mean, cov,
-                           magma_pad(N), mode, want_grad, f_out, g_out, info_out, S(stream));
+  return launch_indiv_eval(count, sel, nmax, off, t, y, idx, theta, theta_stride, mean, cpack,
+                           mode, want_grad, f_out, g_out, info_out, S(stream));
+}
+
+int64_t magma_cpack_stride(int nmax) {
+  if (nmax < 1 || nmax > MAGMA_NSMALL_MAX) return 0;
+  return (int64_t)cpack_ldp(nmax) * small_template_nmax(nmax);
+}
+
+int magma_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
+                           const double* cov, int N, double* cpack, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (N < 1) return fail(2, "N must be >= 1");
+  Prof pf(PROF_GATHER_COV, S(stream));
+  return launch_indiv_gather_cov(M, nmax, off, idx, cov, magma_pad(N), cpack, S(stream));
 }
 
 int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,

@@ -8,6 +8,14 @@
 
 namespace magma {
 
+// Per-individual kernels are instantiated for these row counts (see MAGMA_DISPATCH_NMAX).
+constexpr int small_template_nmax(int nmax) {
+  return nmax <= 8 ? 8 : nmax <= 16 ? 16 : nmax <= 24 ? 24 : nmax <= 32 ? 32 : nmax <= 40 ? 40
+       : nmax <= 48 ? 48 : nmax <= 52 ? 52 : nmax <= 56 ? 56 : 64;
+}
+// Packed C_i (magma_indiv_gather_cov): ldp rows x small_template_nmax columns per individual.
+constexpr int cpack_ldp(int nmax) { return 16 * ((small_template_nmax(nmax) + 15) / 16); }
+
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 int check_hip(hipError_t e, const char* what);

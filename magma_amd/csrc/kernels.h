@@ -16,8 +16,10 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
                          int64_t ldp, double* w, int* info, hipStream_t st);
 int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, const double* t,
                       const double* y, const int* idx, const double* theta, int tstride,
-                      const double* mean, const double* cov, int64_t ldc, int mode, int want_grad,
+                      const double* mean, const double* cpack, int mode, int want_grad,
                       double* f, double* g, int* info, hipStream_t st);
+int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
+                            const double* cov, int64_t ldc, double* cpack, hipStream_t st);
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
                    const int* idx_n, int T, const double* ts, const double* mean_pred,
                    const int* idx_t, const double* cov, int64_t ldc, const double* theta,

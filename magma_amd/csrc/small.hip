@@ -28,6 +28,23 @@ namespace magma {
 
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
+// Diagnostic build only (-DMAGMA_STAMPS): cycle shares of the segments of indiv_eval.
+#ifdef MAGMA_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_INIT() unsigned long long st_prev = stamp_now(); unsigned long long st_acc[10] = {0,0,0,0,0,0,0,0,0,0}
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long st_t = stamp_now(); st_acc[i] += st_t - st_prev; st_prev = st_t; __builtin_amdgcn_sched_barrier(0);} while (0)
+#define STAMP_FLUSH() do { if (threadIdx.x == 0) { for (int q = 0; q < 10; ++q) atomicAdd(&g_stamps[q], st_acc[q]); atomicAdd(&g_stamps[15], 1ull);} } while (0)
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#else
+#define STAMP_INIT()
+#define STAMP(i)
+#define STAMP_FLUSH()
+#endif
+
 // ------------------------------------------------------------------ row build
 // a[c] = K[r][c] for the SE kernel: off-diagonal exp(th1 - h (t_r - t_c)^2), diagonal
 // exp(th1) + sigma^2 (CF:76,103: as.matrix(dist) has a zero diagonal). Identity padding.
@@ -204,34 +221,141 @@ __global__ __launch_bounds__(64) void estep_scatter_kernel(
   }
 }
 
+// ------------------------------------------------------------------ packed C_i = cov[idx_i, idx_i]
+// The hyper-posterior covariance is fixed during an M-step while every individual is evaluated
+// tens of times: the random gather (n^2 isolated 8-byte reads, one cache line each) is done
+// once; evaluations then stream a contiguous block. Slot i holds C_i (zero padded) in the
+// order the evaluation kernel's lanes consume it: [kk][lane][it] = C[16 it + l][4 kk + g]
+// (l = lane & 15, g = lane >> 4; kk < NC / 4, it < NT, NC = the kernel instantiation nmax
+// rounds up to, NT = ceil(NC / 16)). One wavefront-wide 16-byte load then fetches 1 KB of
+// contiguous memory, and by symmetry the same address serves both as the MFMA A fragment of
+// k-block kk and as rows 4 kk + g of C in accumulator layout.
+__global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
+    int M, const int64_t* __restrict__ off, const int* __restrict__ idx,
+    const double* __restrict__ cov, int64_t ldc, double* __restrict__ cpack, int nt, int nc) {
+  __shared__ int ibuf[MAGMA_NSMALL_MAX];
+  for (int i = blockIdx.x; i < M; i += gridDim.x) {
+    const int64_t o = off[i];
+    const int n = (int)(off[i + 1] - o);
+    __syncthreads();
+    if ((int)threadIdx.x < n) ibuf[threadIdx.x] = idx[o + threadIdx.x];
+    __syncthreads();
+    const int tot = 16 * nt * nc;
+    double* out = cpack + (int64_t)i * tot;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+      const int it = e % nt, ln = (e / nt) & 63, kk = e / (64 * nt);
+      const int r = 16 * it + (ln & 15), c = 4 * kk + (ln >> 4);
+      out[e] = (r < n && c < n) ? cov[(int64_t)ibuf[c] * ldc + ibuf[r]] : 0.0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ M-step evaluation
 // mode 0 (logL_GP_mod / gr_GP_mod): K = K(theta, sigma);
 //        f = 1/2 (n log 2pi + log|K| + z'K^-1 z) + 1/2 sum(K^-1 o C),
 //        W = aa' + K^-1 C K^-1 - K^-1, g = -(1/2 sum W o K_nl, 1/2 sum W o dK2, sigma tr W).
 // mode 1 (logL_GP / gr_GP): K = K(theta, sigma) + C; f without the trace term; W = aa' - K^-1.
-// C = cov[idx, idx] gathered from the N x N hyper-posterior covariance (cov == nullptr: zero).
+// C = packed cov[idx, idx] (cpack == nullptr: zero).
 // Workgroup b handles individual sel[b] (sel == nullptr: b), so a lock-step optimiser only
 // launches the problems that are still running.
-// Gradient data flow (one LDS matrix, dynamic): Ks = K^-1 (symmetric: "own element" and
-// "broadcast row" layouts coincide). T' = C K^-1 is accumulated in registers with the own
-// operand C[r][c] gathered straight from the L2-resident cov, then written over Ks as rows;
-// Z = K^-1 T' uses the register-resident row of K^-1 as own operand and broadcast rows of T'.
+//
+// One wavefront per individual, every n^3 stage on v_mfma_f64_16x16x4_f64. The matrix lives
+// in accumulator layout: 16 x 16 tiles, register v of lane (l, g) [l = lane & 15, g = lane >> 4]
+// of tile (it, jt) = element (16 it + g + 4 v, 16 jt + l). MFMA operands: A fragment lane
+// (l, g) = A[l][g], B fragment lane (l, g) = B[g][l]. The identity that removes all operand
+// shuffling: rows 4 kk .. 4 kk + 3 of a matrix held in accumulator layout ARE its B fragment
+// for k-block kk (register kk & 3 of the tiles in tile row kk >> 2).
+//
+//  1. K built in place (identity padded to NMAX, a multiple of 4).
+//  2. Inverse + log-det by a blocked symmetric sweep (Gauss-Jordan without pivoting on an SPD
+//     matrix; its pivots are the squares of the Cholesky diagonal, so log-det and the SPD test
+//     are those of a Cholesky). Block J = 4 pivots: with P = A[J,J], D = P^-1 (4 x 4, every
+//     lane redundantly, LDL'), the sweep is  A <- A - F' B'  - 2 I_J  with
+//       B' = A[J,:] with (P - I) in place of P   (registers: the identity above),
+//       F' = B''  D                               (B' through 2 KB of LDS to transpose it),
+//     which leaves A[i,J] = A[i,J] D, A[J,J] = -D and the Schur complement elsewhere: 16 MFMAs
+//     per block and 12 LDS instructions, instead of 4 x (26 broadcast reads + 52 FMAs).
+//     After NMAX / 4 blocks A = -K^-1.
+//  3. K^-1 -> LDS once (Ks; symmetric, so [k][j] and [j][k] fragment reads coincide).
+//  4. T = C K^-1: A fragments straight from the packed C in global memory, B from Ks.
+//  5. Z = K^-1 T: A fragments from Ks, B fragments = T's registers; only tiles on or below the
+//     diagonal, each contracted with K_nl and dK/dtheta2 as soon as it is complete.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// D = P^-1 and the four sweep pivots of a symmetric positive definite 4 x 4 (lower triangle in
+// p[i][j], i >= j), by LDL'. bad = index + 1 of the first pivot that is not a positive finite
+// number (0 = none); what follows a bad pivot is garbage that the caller discards (info).
+__device__ __forceinline__ void spd4_inverse(const double (&p)[4][4], double (&D)[4][4],
+                                             double (&piv)[4], int& bad) {
+  bad = 0;
+  auto fix = [&](double d, int k) {
+    const bool ok = (d > 0.0) && (d < 1.7e308);
+    bad = (!ok && bad == 0) ? k + 1 : bad;
+    return d;
+  };
+  const double d0 = fix(p[0][0], 0);
+  const double r0 = fast_rcp(d0);
+  const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
+  const double p11 = fma(-l10, p[1][0], p[1][1]);
+  const double p21 = fma(-l20, p[1][0], p[2][1]);
+  const double p31 = fma(-l30, p[1][0], p[3][1]);
+  double p22 = fma(-l20, p[2][0], p[2][2]);
+  double p32 = fma(-l30, p[2][0], p[3][2]);
+  double p33 = fma(-l30, p[3][0], p[3][3]);
+  const double d1 = fix(p11, 1);
+  const double r1 = fast_rcp(d1);
+  const double l21 = p21 * r1, l31 = p31 * r1;
+  p22 = fma(-l21, p21, p22);
+  p32 = fma(-l31, p21, p32);
+  p33 = fma(-l31, p31, p33);
+  const double d2 = fix(p22, 2);
+  const double r2 = fast_rcp(d2);
+  const double l32 = p32 * r2;
+  p33 = fma(-l32, p32, p33);
+  const double d3 = fix(p33, 3);
+  const double r3 = fast_rcp(d3);
+  piv[0] = d0; piv[1] = d1; piv[2] = d2; piv[3] = d3;
+  // M = L^-1 (unit lower)
+  const double m10 = -l10, m21 = -l21, m32 = -l32;
+  const double m20 = -fma(l21, m10, l20);
+  const double m31 = -fma(l32, m21, l31);
+  const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+  // D = M' diag(r) M
+  D[3][3] = r3;
+  D[3][2] = r3 * m32;
+  D[3][1] = r3 * m31;
+  D[3][0] = r3 * m30;
+  D[2][2] = fma(m32, D[3][2], r2);
+  D[2][1] = fma(m32, D[3][1], r2 * m21);
+  D[2][0] = fma(m32, D[3][0], r2 * m20);
+  D[1][1] = fma(m31, D[3][1], fma(m21, r2 * m21, r1));
+  D[1][0] = fma(m31, D[3][0], fma(m21, r2 * m20, r1 * m10));
+  D[0][0] = fma(m30, D[3][0], fma(m20, r2 * m20, fma(m10, r1 * m10, r0)));
+  D[0][1] = D[1][0]; D[0][2] = D[2][0]; D[0][3] = D[3][0];
+  D[1][2] = D[2][1]; D[1][3] = D[3][1]; D[2][3] = D[3][2];
+}
+
 template <int NMAX>
 __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
     int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
-    const double* __restrict__ cov, int64_t ldc, int mode, int want_grad,
+    const double* __restrict__ cpack, int mode, int want_grad,
     double* __restrict__ f_out, double* __restrict__ g_out, int* __restrict__ info_out) {
-  constexpr int LD = NMAX + 2;
+  constexpr int NT = (NMAX + 15) / 16;  // 16 x 16 tiles per dimension
+  constexpr int NK = NMAX / 4;          // blocks of 4 rows / k-blocks
+  constexpr int LD = NMAX;              // row length of Ks
+  static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
   __shared__ double tbuf[64];
   __shared__ double zbuf[64];
   __shared__ double abuf[64];
-  __shared__ int ibuf[64];
-  __shared__ __attribute__((aligned(16))) double colbuf[64];
+  // Ks: NMAX * LD + 16 doubles (fragment reads of the last rows run up to 12 doubles past the
+  // end; what they fetch only reaches masked results). During the sweep its first 256 doubles
+  // are the transposition buffer Pn[64][4].
   extern __shared__ __attribute__((aligned(16))) double Ks[];
 
   const int lane = threadIdx.x;
+  const int l = lane & 15, g = lane >> 4;
   const int io = blockIdx.x;  // slot of theta / f / g / info (compact when sel is given)
   const int i = sel ? sel[io] : io;
   const int64_t o = off[i];
@@ -240,113 +364,271 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
   const double sigma = th[2];
   const SEParams p = se_params(th[0], th[1], sigma);
   const bool rv = lane < n;
-  const bool lv = lane < NMAX;  // lanes beyond the padded matrix own no row
   const double tr = rv ? t[o + lane] : 0.0;
-  const int ir = rv ? idx[o + lane] : 0;
-  const double zr = rv ? (y[o + lane] - mean[ir]) : 0.0;
+  const double zr = rv ? (y[o + lane] - mean[idx[o + lane]]) : 0.0;
   tbuf[lane] = tr;
   zbuf[lane] = zr;
-  ibuf[lane] = ir;
   __syncthreads();
+  STAMP_INIT();
+  const bool have_c = (cpack != nullptr);
+  // packed C_i: Cq[kk * 64 * NT + it] = C[16 it + l][4 kk + g] (see indiv_gather_cov_kernel)
+  const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
+  const bool with_c = (mode == 0 && have_c);
+  // The packed C_i is requested as one batch of 16-byte loads (26 per lane at NMAX = 52) well
+  // before its first use: issued a pair at a time next to their uses, which is what the
+  // compiler does when left alone, they cost NK serial HBM latencies per wavefront.
 
-  double a[NMAX];
-  build_row<NMAX>(a, lane, n, tr, tbuf, p);
-  const bool have_c = (cov != nullptr);
-  const double* crow = cov + ir;  // column-major symmetric: C[r][c] = cov[idx_c * ldc + idx_r]
-  if (mode == 1 && have_c) {
+  // ---- 1. K in accumulator layout (rows >= NMAX are never touched: compile-time skip)
+  v4d A[NT][NT];
+  double tcol[NT];
 #pragma unroll
-    for (int c = 0; c < NMAX; ++c)
-      if (rv && c < n) a[c] += crow[(int64_t)ibuf[c] * ldc];
+  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
+        continue;
+      }
+      const int r = 16 * it + 4 * v + g;
+      const double trow = tbuf[r];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        const double d = trow - tcol[jt];
+        double kv = exp(p.th1 - p.h * d * d);
+        kv = (r == c) ? (p.eth1 + p.sig2) : kv;
+        A[it][jt][v] = (r < n && c < n) ? kv : ((r == c) ? 1.0 : 0.0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
+      }
+    }
   }
-  double logdet;
-  int info;
-  sweep_inverse<NMAX>(a, lane, colbuf, logdet, info);
+  if (mode == 1 && have_c) {  // K + C (C is zero in the padding)
+    double c1[NK][NT];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) c1[kk][it] = Cq[kk * 64 * NT + it];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) A[kk >> 2][jt][kk & 3] += c1[kk][jt];
+  }
+  STAMP(0);
 
-  // alpha = K^-1 z ; ssq = z' alpha
+  // ---- 2. blocked symmetric sweep
+  double pm = 1.0;
+  int pe = 0, info = 0;
+  double* Pn = Ks;
+  double gm[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    gm[h] = (g == h) ? 1.0 : 0.0;
+    asm volatile("" : "+v"(gm[h]));  // opaque: keeps the weights from being folded back to selects
+  }
+#pragma unroll
+  for (int b = 0; b < NK; ++b) {
+    const int it0 = b >> 2, v0 = b & 3;
+    const bool dg = (l == 4 * v0 + g);  // this lane holds a diagonal element of P (tile it0,it0)
+    double bq[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      bq[jt] = A[it0][jt][v0] - ((jt == it0 && dg) ? 1.0 : 0.0);
+      Pn[(16 * jt + l) * 4 + g] = bq[jt];
+    }
+    __syncthreads();
+    double P4[4][4], D[4][4], piv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4 + 2]);
+      P4[r][0] = lo.x; P4[r][1] = lo.y; P4[r][2] = hi.x; P4[r][3] = hi.y;
+      P4[r][r] += 1.0;
+    }
+    int bad;
+    spd4_inverse(P4, D, piv, bad);
+    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int e;
+      pm *= frexp(piv[k], &e);
+      pe += e;
+    }
+    if ((b & 7) == 7) {  // keep the mantissa product in range
+      int e;
+      pm = frexp(pm, &e);
+      pe += e;
+    }
+    // evaluate now: otherwise all NMAX pivots stay in registers until the end of the sweep
+    asm volatile("" : "+v"(pm), "+v"(pe));
+    // this lane's column g of D, picked with 0/1 weights (exact). A select chain here is turned
+    // into divergent branches around the whole D computation by hipcc.
+    double dc[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      dc[h] = fma(gm[3], D[h][3], fma(gm[2], D[h][2], fma(gm[1], D[h][1], gm[0] * D[h][0])));
+    double nf[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4 + 2]);
+      nf[it] = -fma(hi.y, dc[3], fma(hi.x, dc[2], fma(lo.y, dc[1], lo.x * dc[0])));
+    }
+    __syncthreads();  // Pn is rewritten by the next block
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+        A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nf[it], bq[jt], A[it][jt], 0, 0, 0);
+    A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+  }
+  const double logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818;
+  STAMP(1);
+
+  // ---- 3. K^-1 = -A to LDS
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) continue;
+      const int r = 16 * it + 4 * v + g;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -A[it][jt][v];
+      }
+    }
+  __syncthreads();
+  STAMP(4);
+
+  // The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52), issued once the
+  // accumulator tiles are dead and consumed after alpha. (Left alone the compiler issues them a
+  // pair at a time next to their uses: NK serial HBM latencies per wavefront.)
+  __builtin_amdgcn_sched_barrier(0);
+  double cf[NK][NT];
+  if (with_c) {
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) cf[kk][it] = Cq[kk * 64 * NT + it];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // alpha = K^-1 z ; ssq = z' alpha  (lane r owns row r; column reads by symmetry)
   double alpha = 0.0;
+  {
+    const int lr = lane < NMAX ? lane : 0;
 #pragma unroll
-  for (int c = 0; c < NMAX; ++c) alpha = fma(a[c], zbuf[c], alpha);
-  abuf[lane] = alpha;
+    for (int c = 0; c < NMAX; c += 2) {
+      const double2 zz = *reinterpret_cast<const double2*>(&zbuf[c]);
+      alpha = fma(Ks[c * LD + lr], zz.x, alpha);
+      alpha = fma(Ks[(c + 1) * LD + lr], zz.y, alpha);
+    }
+    alpha = lane < NMAX ? alpha : 0.0;
+  }
   const double ssq = wave_sum(zr * alpha);
+  STAMP(2);
 
-  const bool grad_c = want_grad && mode == 0 && have_c;
-  double cor = 0.0;
-  double z[NMAX];  // row r of K^-1 C K^-1 (zero when there is no C term)
-#pragma unroll
-  for (int c = 0; c < NMAX; ++c) z[c] = 0.0;
-  if (mode == 0 && have_c && !grad_c) {
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) {
-      const double cv = (rv && c < n) ? crow[(int64_t)ibuf[c] * ldc] : 0.0;
-      cor = fma(a[c], cv, cor);
-    }
-  }
-  if (grad_c) {
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c)
-      if (lv) Ks[c * LD + lane] = a[c];
-    __syncthreads();
-    // T'[r][d] = sum_c C[r][c] K^-1[c][d], trace term on the way; own C prefetched 2 ahead
-    double cv0 = (rv && 0 < n) ? crow[(int64_t)ibuf[0] * ldc] : 0.0;
-    double cv1 = (rv && 1 < n) ? crow[(int64_t)ibuf[1] * ldc] : 0.0;
-    for (int c = 0; c < n; ++c) {
-      const double cv = cv0;
-      cv0 = cv1;
-      cv1 = (rv && c + 2 < n) ? crow[(int64_t)ibuf[c + 2] * ldc] : 0.0;
-      const double kown = lv ? Ks[c * LD + lane] : 0.0;
-      cor = fma(kown, cv, cor);
-      const double* krow = &Ks[c * LD];
-#pragma unroll
-      for (int d = 0; d < NMAX; d += 2) {
-        const double2 kk = *reinterpret_cast<const double2*>(&krow[d]);
-        z[d] = fma(cv, kk.x, z[d]);
-        z[d + 1] = fma(cv, kk.y, z[d + 1]);
-      }
-    }
-    __syncthreads();
-    // rows of T' over Ks (lane d writes row d), then Z[r][b] = sum_d K^-1[r][d] T'[d][b]
-#pragma unroll
-    for (int b = 0; b < NMAX; ++b) {
-      if (lv) Ks[lane * LD + b] = z[b];
-      z[b] = 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < NMAX; ++d) {
-      const double kown = a[d];
-      const double* trow = &Ks[d * LD];
-#pragma unroll
-      for (int b = 0; b < NMAX; b += 2) {
-        const double2 tt = *reinterpret_cast<const double2*>(&trow[b]);
-        z[b] = fma(kown, tt.x, z[b]);
-        z[b + 1] = fma(kown, tt.y, z[b + 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // no load hoisting across rows: register pressure
-    }
-  }
-  if (mode == 0 && have_c) cor = wave_sum(cor);
-  const double f = 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor;
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-  if (lane == 0) {
-    f_out[io] = (info == 0) ? f : nanv;
-    info_out[io] = info;
+  if (!want_grad) {
+    double cor = 0.0;
+    if (with_c) {  // sum(K^-1 o C) in accumulator layout, C read by symmetry
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          cor = fma(Ks[(4 * kk + g) * LD + 16 * jt + l], cf[kk][jt], cor);
+      cor = wave_sum(cor);
+    }
+    STAMP(3);
+    if (lane == 0) {
+      f_out[io] = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
+      info_out[io] = info;
+    }
+    STAMP_FLUSH();
+    return;
   }
-  if (!want_grad) return;
+  abuf[lane] = alpha;
+
+  // ---- 4./5. by column block jt: Tc = (C K^-1)[:, jt] (NT tiles), then Z[at][jt] = K^-1 Tc for
+  // at >= jt, contracted at once. Only cf (the packed C) stays live across blocks.
   __syncthreads();  // abuf visible
+  double cor = 0.0;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-  for (int b = 0; b < NMAX; ++b) {
-    const double d = tr - tbuf[b];
-    const double gq = p.h * d * d;
-    double knl = exp(p.th1 - gq);
-    knl = (b == lane) ? p.eth1 : knl;
-    const double W = fma(alpha, abuf[b], z[b] - a[b]);
-    const double wk = (rv && b < n) ? W * knl : 0.0;
-    s1 += wk;
-    s2 = fma(wk, gq, s2);  // dK/dtheta2 = gq * K_nl, zero on the diagonal (gq = 0 there)
-    s3 += (b == lane && rv) ? W : 0.0;
+  for (int jt = 0; jt < NT; ++jt) {
+    v4d Tc[NT];
+    v4d Z[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      Tc[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+      Z[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    if (with_c) {
+      double bf = Ks[g * LD + 16 * jt + l];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const double b0 = bf;
+        if (kk + 1 < NK) bf = Ks[(4 * (kk + 1) + g) * LD + 16 * jt + l];
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+          Tc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[kk][it], b0, Tc[it], 0, 0, 0);
+      }
+      // tr(C K^-1): the diagonal of T sits in the diagonal tiles where g + 4v == l
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (16 * jt + 4 * v < NMAX) cor += (g + 4 * v == l) ? Tc[jt][v] : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+      double ka[NT];
+#pragma unroll
+      for (int at = jt; at < NT; ++at) ka[at] = Ks[g * LD + 16 * at + l];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        double k0[NT];
+#pragma unroll
+        for (int at = jt; at < NT; ++at) {
+          k0[at] = ka[at];
+          if (kk + 1 < NK) ka[at] = Ks[(4 * (kk + 1) + g) * LD + 16 * at + l];
+        }
+#pragma unroll
+        for (int at = jt; at < NT; ++at)
+          Z[at] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0[at], Tc[kk >> 2][kk & 3], Z[at], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    // element (ra, cj), ra = 16 at + 4v + g, cj = 16 jt + l
+    const int cj = 16 * jt + l;
+    const double acj = abuf[cj];
+#pragma unroll
+    for (int at = jt; at < NT; ++at) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (16 * at + 4 * v >= NMAX) continue;
+        const int ra = 16 * at + 4 * v + g;
+        const bool ok = ra < n && cj < n;
+        const double d = tbuf[ra] - tcol[jt];
+        const double gq = p.h * d * d;
+        double knl = exp(p.th1 - gq);
+        knl = (ra == cj) ? p.eth1 : knl;
+        const double W = fma(abuf[ra], acj, Z[at][v] - Ks[ra * LD + cj]);
+        const double wt = (jt == at) ? 1.0 : 2.0;  // tiles above the diagonal by symmetry
+        const double wk = ok ? wt * W * knl : 0.0;
+        s1 += wk;
+        s2 = fma(wk, gq, s2);  // dK/dtheta2 = gq * K_nl, zero on the diagonal (gq = 0 there)
+        s3 += (ok && ra == cj) ? W : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
+  if (with_c) cor = wave_sum(cor);
+  if (lane == 0) {
+    f_out[io] = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
+    info_out[io] = info;
+  }
+  STAMP(7);
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   s3 = wave_sum(s3);
@@ -355,6 +637,8 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
     g_out[3 * (int64_t)io + 1] = (info == 0) ? -0.5 * s2 : nanv;
     g_out[3 * (int64_t)io + 2] = (info == 0) ? -sigma * s3 : nanv;
   }
+  STAMP(8);
+  STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------ prediction (MG:172-180)
@@ -425,6 +709,7 @@ __global__ __launch_bounds__(64) void pred_gp_kernel(
 }
 
 // ------------------------------------------------------------------ launchers
+// (the instantiation list is mirrored by small_template_nmax() in common.h)
 #define MAGMA_DISPATCH_NMAX(nmax, CALL)                 \
   do {                                                  \
     if ((nmax) <= 8) { CALL(8); }                       \
@@ -474,33 +759,41 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
 template <int NM>
 static int launch_indiv_eval_t(int nsel, const int* sel, const int64_t* off, const double* t,
                                const double* y, const int* idx, const double* theta, int tstride,
-                               const double* mean, const double* cov, int64_t ldc, int mode,
-                               int want_grad, double* f, double* g, int* info, hipStream_t st) {
-  const size_t full = (size_t)NM * (NM + 2) * sizeof(double);
-  const size_t dyn = (want_grad && mode == 0 && cov != nullptr) ? full : 0;
+                               const double* mean, const double* cpack, int mode, int want_grad,
+                               double* f, double* g, int* info, hipStream_t st) {
+  const size_t dyn = ((size_t)NM * NM + 16) * sizeof(double);  // >= the 64 NT doubles of Pn
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)full);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     attr_set = true;
   }
   hipLaunchKernelGGL(indiv_eval_kernel<NM>, dim3(nsel), dim3(64), dyn, st, nsel, sel, off, t, y,
-                     idx, theta, tstride, mean, cov, ldc, mode, want_grad, f, g, info);
+                     idx, theta, tstride, mean, cpack, mode, want_grad, f, g, info);
   return check_hip(hipGetLastError(), "indiv_eval");
 }
 
 int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, const double* t,
                       const double* y, const int* idx, const double* theta, int tstride,
-                      const double* mean, const double* cov, int64_t ldc, int mode, int want_grad,
+                      const double* mean, const double* cpack, int mode, int want_grad,
                       double* f, double* g, int* info, hipStream_t st) {
   if (nsel <= 0) return 0;
   int rc = 0;
-#define CALL(NM)                                                                              \
-  rc = launch_indiv_eval_t<NM>(nsel, sel, off, t, y, idx, theta, tstride, mean, cov, ldc,    \
+#define CALL(NM)                                                                          \
+  rc = launch_indiv_eval_t<NM>(nsel, sel, off, t, y, idx, theta, tstride, mean, cpack,   \
                                mode, want_grad, f, g, info, st)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return rc;
+}
+
+int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
+                            const double* cov, int64_t ldc, double* cpack, hipStream_t st) {
+  if (M <= 0) return 0;
+  const int grid = M < 65536 ? M : 65536;
+  hipLaunchKernelGGL(indiv_gather_cov_kernel, dim3(grid), dim3(256), 0, st, M, off, idx, cov, ldc,
+                     cpack, cpack_ldp(nmax) / 16, small_template_nmax(nmax));
+  return check_hip(hipGetLastError(), "indiv_gather_cov");
 }
 
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
@@ -520,3 +813,14 @@ int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean
 }
 
 }  // namespace magma
+
+#ifdef MAGMA_STAMPS
+extern "C" int magma_dbg_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(magma::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(magma::g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -128,6 +128,9 @@ class HipBackend:
         wbytes = int(self.lib.magma_workspace_bytes(ds.N))
         self.work = torch.empty((wbytes + 7) // 8, dtype=f64, device=dev)
         self.cov = self.P  # alias: after estep_finish P holds the covariance
+        self.cpack = torch.zeros(Mb * int(self.lib.magma_cpack_stride(self.nmax)), dtype=f64,
+                                 device=dev)
+        self._cpack_ok = False  # cpack holds cov[idx_i, idx_i] of the current cov
         self.n_evals = 0  # individual objective evaluations launched (for roofline figures)
         self._side = None
         self._a0_key = None  # (theta1, theta2, pen) whose K_0^-1 sits in the workspace
@@ -193,12 +196,14 @@ class HipBackend:
         c = np.eye(self.Np)
         c[:self.N, :self.N] = cov
         self.P.copy_(self.torch.from_numpy(c.T.reshape(-1).copy()))
+        self._cpack_ok = False
 
     # -- E-step
     def estep_scatter(self, theta):
         """Zero P, w and scatter this shard's K_i^-1 / K_i^-1 y_i. Returns (P, w) tensors for
         the caller to all-reduce, and the number of flagged (non-SPD) individuals."""
         stride = self._set_theta(theta)
+        self._cpack_ok = False
         self.P.zero_()
         self.w.zero_()
         if self.M > 0:
@@ -255,9 +260,13 @@ class HipBackend:
             stride = 3
         if want_grad:
             self.n_evals += cnt
+        if use_cov and not self._cpack_ok:  # once per hyper-posterior, not per evaluation
+            _lib.call("magma_indiv_gather_cov", self.M, self.nmax, _ptr(self.off), _ptr(self.idx),
+                      _ptr(self.cov), self.N, _ptr(self.cpack), self.stream())
+            self._cpack_ok = True
         _lib.call("magma_indiv_eval", int(mode), self.M, self.nmax, _ptr(self.off), _ptr(self.t),
                   _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, _ptr(self.mean),
-                  _ptr(self.cov if use_cov else None), self.N, int(bool(want_grad)), _ptr(sel),
+                  _ptr(self.cpack if use_cov else None), int(bool(want_grad)), _ptr(sel),
                   nsel, _ptr(self.f), _ptr(self.g), _ptr(self.info), self.stream())
         self.h_f[:cnt].copy_(self.f[:cnt], non_blocking=True)
         if want_grad:

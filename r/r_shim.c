@@ -23,7 +23,7 @@ typedef struct {
   int64_t *off;          /* device */
   double *t, *y, *grid;  /* device */
   int *idx;              /* device */
-  double *theta, *f, *g, *P, *w, *mean, *m0;
+  double *theta, *f, *g, *P, *w, *mean, *m0, *cpack;
   int *info;
   void *work;
 } session;
@@ -31,7 +31,7 @@ typedef struct {
 static void sess_free(session *s) {
   if (!s) return;
   void *p[] = {s->off, s->t, s->y, s->grid, s->idx, s->theta, s->f, s->g, s->P, s->w,
-               s->mean, s->m0, s->info, s->work};
+               s->mean, s->m0, s->info, s->work, s->cpack};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i)
     if (p[i]) magma_dev_free(p[i]);
   free(s);
@@ -85,6 +85,7 @@ SEXP magmahip_session(SEXP off, SEXP t, SEXP y, SEXP idx, SEXP grid) {
     if (!rc) rc = magma_dev_malloc((void **)&s->w, sizeof(double) * s->Np);
     if (!rc) rc = magma_dev_malloc((void **)&s->mean, sizeof(double) * s->Np);
     if (!rc) rc = magma_dev_malloc((void **)&s->m0, sizeof(double) * s->Np);
+    if (!rc) rc = magma_dev_malloc((void **)&s->cpack, sizeof(double) * Mb * magma_cpack_stride(s->nmax));
     if (!rc) rc = magma_dev_malloc(&s->work, magma_workspace_bytes(s->N));
     if (!rc) rc = magma_stream_sync(NULL);
   }
@@ -125,6 +126,8 @@ SEXP magmahip_e_step(SEXP sx, SEXP theta0, SEXP pen, SEXP theta_i, SEXP m0) {
                                     s->N, s->P, s->w, s->info, NULL);
   if (!rc) rc = magma_estep_finish(s->N, s->grid, REAL(theta0)[0], REAL(theta0)[1], REAL(pen)[0],
                                    s->m0, s->P, s->w, s->mean, s->work, 0, NULL, &hinfo, NULL);
+  if (!rc && hinfo == 0)
+    rc = magma_indiv_gather_cov(s->M, s->nmax, s->off, s->idx, s->P, s->N, s->cpack, NULL);
   if (rc) Rf_error("magmahip: %s", magma_last_error());
   SEXP mean = PROTECT(allocVector(REALSXP, s->N));
   SEXP cov = PROTECT(allocMatrix(REALSXP, s->N, s->N));
@@ -154,6 +157,7 @@ SEXP magmahip_set_posterior(SEXP sx, SEXP mean, SEXP cov) {
   int rc = put_vec_padded(s, s->mean, mean);
   if (!rc) rc = up((void **)&tmp, REAL(cov), sizeof(double) * (size_t)s->N * s->N);
   if (!rc) rc = magma_copy_pad(s->N, tmp, s->N, s->P, 0, NULL);
+  if (!rc) rc = magma_indiv_gather_cov(s->M, s->nmax, s->off, s->idx, s->P, s->N, s->cpack, NULL);
   if (!rc) rc = magma_stream_sync(NULL);
   if (tmp) magma_dev_free(tmp);
   if (rc) Rf_error("magmahip: %s", magma_last_error());
@@ -166,7 +170,7 @@ SEXP magmahip_indiv_eval(SEXP sx, SEXP theta_i, SEXP want_grad, SEXP mode) {
   const int stride = LENGTH(theta_i) == 3 ? 0 : 3, wg = asLogical(want_grad);
   int rc = magma_memcpy_h2d(s->theta, REAL(theta_i), sizeof(double) * LENGTH(theta_i), NULL);
   if (!rc) rc = magma_indiv_eval(asInteger(mode), s->M, s->nmax, s->off, s->t, s->y, s->idx,
-                                 s->theta, stride, s->mean, s->P, s->N, wg, NULL, 0, s->f, s->g,
+                                 s->theta, stride, s->mean, s->cpack, wg, NULL, 0, s->f, s->g,
                                  s->info, NULL);
   if (rc) Rf_error("magmahip: %s", magma_last_error());
   SEXP f = PROTECT(allocVector(REALSXP, s->M));

@@ -19,7 +19,7 @@ def timeit(fn, reps=5):
 st=be.stream()
 def ev(grad):
     be._set_theta(thi)
-    _lib.call("magma_indiv_eval",0,be.M,be.nmax,C.c_void_p(be.off.data_ptr()),C.c_void_p(be.t.data_ptr()),C.c_void_p(be.y.data_ptr()),C.c_void_p(be.idx.data_ptr()),C.c_void_p(be.theta.data_ptr()),3,C.c_void_p(be.mean.data_ptr()),C.c_void_p(be.cov.data_ptr()),be.N,grad,None,0,C.c_void_p(be.f.data_ptr()),C.c_void_p(be.g.data_ptr()),C.c_void_p(be.info.data_ptr()),st)
+    _lib.call("magma_indiv_eval",0,be.M,be.nmax,C.c_void_p(be.off.data_ptr()),C.c_void_p(be.t.data_ptr()),C.c_void_p(be.y.data_ptr()),C.c_void_p(be.idx.data_ptr()),C.c_void_p(be.theta.data_ptr()),3,C.c_void_p(be.mean.data_ptr()),C.c_void_p(be.cpack.data_ptr()),grad,None,0,C.c_void_p(be.f.data_ptr()),C.c_void_p(be.g.data_ptr()),C.c_void_p(be.info.data_ptr()),st)
 print("indiv_eval f+g  ms", timeit(lambda: ev(1)))
 print("indiv_eval f    ms", timeit(lambda: ev(0)))
 P2=torch.zeros_like(be.P); w2=torch.zeros_like(be.w)

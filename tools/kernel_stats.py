@@ -4,7 +4,7 @@ src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only",
        "-munsafe-fp-atomics", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000",
-       "-Rpass-analysis=kernel-resource-usage",
+       "-Rpass-analysis=kernel-resource-usage", *sys.argv[3:],
        "-x", "hip", "-c", src, "-o", "/dev/null"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
