@@ -120,6 +120,21 @@ int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double
 int64_t magma_cpack_stride(int nmax);
 int magma_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                            const double* cov, int N, double* cpack, void* stream);
+/* m_step for individual hyper-parameters (CF:419-432: one optim() per individual, mode 0) or
+ * train_new_gp's optimisation (MG:93-94, mode 1), the whole loop run natively: M independent
+ * L-BFGS-B problems advance in lock step (magma_lbfgsb_*), each round evaluating only the
+ * problems still running with one magma_indiv_eval-type launch. h_theta0[3M] (host): starting
+ * points. d_theta[3M], d_sel[M], d_f[M], d_g[3M], d_info[M]: device scratch owned by the caller.
+ * Host outputs: h_theta_out[3M] (NaN for a problem that could not start), h_f_out[M] (optional),
+ * h_f_x0[M] (optional: objective at the starting point, i.e. the individual's term of
+ * logL_monitoring at the old hyper-parameters), h_iters, h_nfev, h_status[M] (optional, as
+ * magma_lbfgsb_result), h_rounds, h_nevals (optional: launches and evaluations). Synchronises. */
+int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const double* t,
+                      const double* y, const int* idx, const double* mean, const double* cpack,
+                      const double* h_theta0, int m, double factr, double pgtol, int maxit,
+                      double* d_theta, int* d_sel, double* d_f, double* d_g, int* d_info,
+                      double* h_theta_out, double* h_f_out, double* h_f_x0, int* h_iters,
+                      int* h_nfev, int* h_status, int* h_rounds, int64_t* h_nevals, void* stream);
 /* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
  * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
  * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */
@@ -157,6 +172,11 @@ magma_lbfgsb* magma_lbfgsb_create(int B, int d, const double* h_x0, int m, doubl
                                   double pgtol, int maxit);
 int magma_lbfgsb_ask(magma_lbfgsb* s, double* h_x, unsigned char* h_active, int* h_nactive);
 int magma_lbfgsb_tell(magma_lbfgsb* s, const double* h_f, const double* h_g);
+/* The same with compact I/O, O(running problems) per call: h_sel[k] = index of the k-th running
+ * problem (ascending), h_x[k*d..] its trial point; tell takes values in that order. */
+int magma_lbfgsb_ask_compact(magma_lbfgsb* s, int* h_sel, double* h_x, int* h_nactive);
+int magma_lbfgsb_tell_compact(magma_lbfgsb* s, int n, const int* h_sel, const double* h_f,
+                              const double* h_g);
 int magma_lbfgsb_result(magma_lbfgsb* s, double* h_x, double* h_f, int* h_iters, int* h_nfev,
                         int* h_status);
 void magma_lbfgsb_destroy(magma_lbfgsb* s);

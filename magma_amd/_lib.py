@@ -52,6 +52,11 @@ SIGNATURES = {
     "magma_lbfgsb_create": (_p, [_i, _i, _p, _i, _d, _d, _i]),
     "magma_lbfgsb_ask": (_i, [_p, _p, _p, C.POINTER(_i)]),
     "magma_lbfgsb_tell": (_i, [_p, _p, _p]),
+    "magma_lbfgsb_ask_compact": (_i, [_p, _p, _p, C.POINTER(_i)]),
+    "magma_lbfgsb_tell_compact": (_i, [_p, _i, _p, _p, _p]),
+    "magma_indiv_mstep": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _d, _d, _i,
+                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i),
+                               C.POINTER(_i64), _p]),
     "magma_lbfgsb_result": (_i, [_p, _p, _p, _p, _p, _p]),
     "magma_lbfgsb_destroy": (None, [_p]),
 }

@@ -222,6 +222,94 @@ int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double
                            mode, want_grad, f_out, g_out, info_out, S(stream));
 }
 
+// Pinned staging of magma_indiv_mstep, per host thread, grown on demand and kept.
+namespace {
+struct MstepStage {
+  size_t cap = 0;
+  int* sel = nullptr;
+  double *theta = nullptr, *f = nullptr, *g = nullptr;
+  int ensure(size_t M) {
+    if (M <= cap) return 0;
+    release();
+    const size_t c = M + M / 2 + 64;
+    if (hipHostMalloc((void**)&sel, c * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&theta, 3 * c * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&f, c * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&g, 3 * c * sizeof(double)) != hipSuccess) {
+      release();
+      return fail(3, "magma_indiv_mstep: pinned staging allocation failed");
+    }
+    cap = c;
+    return 0;
+  }
+  void release() {
+    if (sel) (void)hipHostFree(sel);
+    if (theta) (void)hipHostFree(theta);
+    if (f) (void)hipHostFree(f);
+    if (g) (void)hipHostFree(g);
+    sel = nullptr;
+    theta = f = g = nullptr;
+    cap = 0;
+  }
+};
+thread_local MstepStage g_stage;
+}  // namespace
+
+int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const double* t,
+                      const double* y, const int* idx, const double* mean, const double* cpack,
+                      const double* h_theta0, int m, double factr, double pgtol, int maxit,
+                      double* d_theta, int* d_sel, double* d_f, double* d_g, int* d_info,
+                      double* h_theta_out, double* h_f_out, double* h_f_x0, int* h_iters,
+                      int* h_nfev, int* h_status, int* h_rounds, int64_t* h_nevals, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
+  if (h_rounds) *h_rounds = 0;
+  if (h_nevals) *h_nevals = 0;
+  if (M == 0) return 0;
+  if (int rc = g_stage.ensure((size_t)M)) return rc;
+  hipStream_t st = S(stream);
+  magma_lbfgsb* opt = magma_lbfgsb_create(M, 3, h_theta0, m, factr, pgtol, maxit);
+  if (!opt) return fail(2, "magma_indiv_mstep: bad optimiser parameters");
+  int rc = 0, rounds = 0;
+  int64_t nevals = 0;
+  for (;;) {
+    int na = 0;
+    magma_lbfgsb_ask_compact(opt, g_stage.sel, g_stage.theta, &na);
+    if (na == 0) break;
+    const bool all = (na == M);
+    if (!all &&
+        (rc = check_hip(hipMemcpyAsync(d_sel, g_stage.sel, sizeof(int) * na, hipMemcpyHostToDevice, st),
+                        "mstep sel h2d")))
+      break;
+    if ((rc = check_hip(hipMemcpyAsync(d_theta, g_stage.theta, sizeof(double) * 3 * na,
+                                       hipMemcpyHostToDevice, st), "mstep theta h2d")))
+      break;
+    {
+      Prof pf(PROF_INDIV_EVAL, st);
+      rc = launch_indiv_eval(na, all ? nullptr : d_sel, nmax, off, t, y, idx, d_theta, 3, mean,
+                             cpack, mode, 1, d_f, d_g, d_info, st);
+    }
+    if (rc) break;
+    if ((rc = check_hip(hipMemcpyAsync(g_stage.f, d_f, sizeof(double) * na, hipMemcpyDeviceToHost, st),
+                        "mstep f d2h")))
+      break;
+    if ((rc = check_hip(hipMemcpyAsync(g_stage.g, d_g, sizeof(double) * 3 * na,
+                                       hipMemcpyDeviceToHost, st), "mstep g d2h")))
+      break;
+    if ((rc = check_hip(hipStreamSynchronize(st), "mstep sync"))) break;
+    if (rounds == 0 && h_f_x0)
+      for (int k = 0; k < na; ++k) h_f_x0[g_stage.sel[k]] = g_stage.f[k];
+    magma_lbfgsb_tell_compact(opt, na, g_stage.sel, g_stage.f, g_stage.g);
+    ++rounds;
+    nevals += na;
+  }
+  if (!rc) magma_lbfgsb_result(opt, h_theta_out, h_f_out, h_iters, h_nfev, h_status);
+  magma_lbfgsb_destroy(opt);
+  if (h_rounds) *h_rounds = rounds;
+  if (h_nevals) *h_nevals = nevals;
+  return rc;
+}
+
 int64_t magma_cpack_stride(int nmax) {
   if (nmax < 1 || nmax > MAGMA_NSMALL_MAX) return 0;
   return (int64_t)cpack_ldp(nmax) * small_template_nmax(nmax);

@@ -213,6 +213,7 @@ struct magma_lbfgsb {
   double factr, pgtol;
   std::vector<Problem> pr;
   std::vector<double> x, g, xold, gold, dir, xtrial, S, Y, rho;
+  std::vector<int> act;  // problems still running, ascending (compact ask/tell)
 
   double* vx(std::vector<double>& v, int b) { return v.data() + (size_t)b * d; }
   double* sp(int b, int slot) { return S.data() + ((size_t)b * m + slot) * d; }
@@ -438,6 +439,8 @@ magma_lbfgsb* magma_lbfgsb_create(int B, int d, const double* h_x0, int m, doubl
   s->S.assign(n * m, 0.0);
   s->Y.assign(n * m, 0.0);
   s->rho.assign((size_t)B * m, 0.0);
+  s->act.resize(B);
+  for (int b = 0; b < B; ++b) s->act[b] = b;
   return s;
 }
 
@@ -459,6 +462,34 @@ int magma_lbfgsb_tell(magma_lbfgsb* s, const double* h_f, const double* h_g) {
   if (!s) return 2;
   for (int b = 0; b < s->B; ++b)
     if (s->pr[b].status == 0) s->tell_one(b, h_f[b], h_g + (size_t)b * s->d);
+  return 0;
+}
+
+int magma_lbfgsb_ask_compact(magma_lbfgsb* s, int* h_sel, double* h_x, int* h_nactive) {
+  if (!s) return 2;
+  size_t k = 0;
+  for (size_t q = 0; q < s->act.size(); ++q) {
+    const int b = s->act[q];
+    if (s->pr[b].status != 0) continue;  // ended by a full-size tell
+    s->act[k] = b;
+    h_sel[k] = b;
+    const double* src = s->vx(s->xtrial, b);
+    std::copy(src, src + s->d, h_x + k * s->d);
+    ++k;
+  }
+  s->act.resize(k);
+  *h_nactive = (int)k;
+  return 0;
+}
+
+int magma_lbfgsb_tell_compact(magma_lbfgsb* s, int n, const int* h_sel, const double* h_f,
+                              const double* h_g) {
+  if (!s) return 2;
+  for (int k = 0; k < n; ++k) {
+    const int b = h_sel[k];
+    if (b < 0 || b >= s->B) return 2;
+    if (s->pr[b].status == 0) s->tell_one(b, h_f[k], h_g + (size_t)k * s->d);
+  }
   return 0;
 }
 

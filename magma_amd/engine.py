@@ -284,6 +284,36 @@ class HipBackend:
             g[ids] = gc
         return f, g
 
+    def indiv_mstep(self, theta_start, mode=0, use_cov=True, m=5, factr=1e7, pgtol=0.0,
+                    maxit=100):
+        """All of this shard's per-individual L-BFGS-B problems, loop and all, in one native
+        call (magma_indiv_mstep). Returns the dict minimize_batch returns."""
+        M = self.M
+        if M == 0:
+            z = np.zeros(0)
+            return {"x": np.zeros((0, 3)), "f": z, "f_x0": z, "iters": z.astype(np.int32),
+                    "nfev": z.astype(np.int32), "status": z.astype(np.int32), "rounds": 0}
+        x0 = np.ascontiguousarray(theta_start, dtype=np.float64)
+        assert x0.shape == (M, 3), x0.shape
+        if use_cov and not self._cpack_ok:
+            _lib.call("magma_indiv_gather_cov", M, self.nmax, _ptr(self.off), _ptr(self.idx),
+                      _ptr(self.cov), self.N, _ptr(self.cpack), self.stream())
+            self._cpack_ok = True
+        x = np.empty((M, 3))
+        f, fx0 = np.empty(M), np.empty(M)
+        iters, nfev, status = (np.empty(M, dtype=np.int32) for _ in range(3))
+        rounds, nev = C.c_int(0), C.c_int64(0)
+        hp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _lib.call("magma_indiv_mstep", int(mode), M, self.nmax, _ptr(self.off), _ptr(self.t),
+                  _ptr(self.y), _ptr(self.idx), _ptr(self.mean),
+                  _ptr(self.cpack if use_cov else None), hp(x0), int(m), float(factr),
+                  float(pgtol), int(maxit), _ptr(self.theta), _ptr(self.sel), _ptr(self.f),
+                  _ptr(self.g), _ptr(self.info), hp(x), hp(f), hp(fx0), hp(iters), hp(nfev),
+                  hp(status), C.byref(rounds), C.byref(nev), self.stream())
+        self.n_evals += int(nev.value)
+        return {"x": x, "f": f, "f_x0": fx0, "iters": iters, "nfev": nfev, "status": status,
+                "rounds": int(rounds.value)}
+
     def theta0_eval(self, theta0, pen_diag, want_grad=True):
         out = (C.c_double * 3)()
         info = C.c_int(0)
@@ -369,6 +399,7 @@ class Engine:
         factory = backend_factory or (lambda d, lo, hi: HipBackend(d, lo, hi, device))
         self.be = factory(ds, self.lo, self.hi)
         self.stats = {"theta0_evals": 0, "indiv_rounds": 0, "common_evals": 0, "flagged": 0}
+        self.native_mstep = True  # False: drive the theta_i rounds from Python (minimize_batch)
 
     # ------------------------------------------------------------ E-step (CF:371-395)
     def e_step(self, theta0, theta_i, pen_diag, m0):
@@ -441,7 +472,11 @@ class Engine:
                 self.stats["indiv_rounds"] += 1
                 return self.be.indiv_eval(x, True, active=act)
             if self.hi > self.lo:
-                ri = minimize_batch(theta_i[self.lo:self.hi], evi, **kw)
+                if hasattr(self.be, "indiv_mstep") and self.native_mstep:
+                    ri = self.be.indiv_mstep(theta_i[self.lo:self.hi], **kw)
+                    self.stats["indiv_rounds"] += ri["rounds"]
+                else:
+                    ri = minimize_batch(theta_i[self.lo:self.hi], evi, **kw)
                 loc, fsum = ri["x"], float(np.sum(ri["f_x0"]))
             else:
                 loc, fsum = np.zeros((0, 3)), 0.0

@@ -290,3 +290,32 @@ def test_em_iteration_shortcuts_equal_explicit_monitoring(gpu):
         c1, c2 = eng.be.get_cov(), cold.be.get_cov()
         assert np.abs(c1 - c2).max() < 1e-12 * np.abs(c2).max()
         assert abs(eng.last_f0 - cold.last_f0) <= 1e-11 * abs(cold.last_f0)
+
+
+def test_native_mstep_loop_equals_python_driven_loop(gpu):
+    """magma_indiv_mstep (C++ round loop, compact ask/tell) against minimize_batch driving
+    magma_indiv_eval from Python: same optimiser, same evaluations -> identical results."""
+    from magma_amd.engine import Dataset, Engine
+    rng = np.random.default_rng(23)
+    db = _ragged_db(rng, [5, 30, 17, 50, 42, 30, 8, 64])
+    ids = orc.unique_in_order(db["ID"])
+    hp = _random_hp(rng, ids)
+    th0 = hp["theta_0"]
+    thi = np.array([hp["theta_i"][i] for i in ids])
+    ds = Dataset(db)
+    res = []
+    eng = Engine(ds)  # one E-step for both (the scatter's atomics are not bitwise repeatable)
+    eng.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.3)
+    for native in (True, False):
+        eng.native_mstep = native
+        eng.stats["indiv_rounds"] = 0
+        n0, ni = eng.m_step(th0, thi, False)
+        res.append((n0, ni, eng.last_sum_fi, eng.stats["indiv_rounds"]))
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    # and against the oracle's m_step with scipy's L-BFGS-B
+    par = orc.e_step(db, 0.3, orc.kernel, orc.kernel, hp)
+    new = orc.m_step(db, hp, par["mean"], par["cov"], orc.kernel, orc.kernel, 0.3, False)
+    exp = np.array([new["theta_i"][i] for i in ids])
+    assert np.abs(res[0][1] - exp).max() < 1e-6 * max(1.0, np.abs(exp).max())
