@@ -44,6 +44,27 @@ PROF_NAMES = ["gemm_nt(T=Kinv*C)", "theta0_contract", "spd_inverse", "indiv_eval
               "indiv_gather_cov"]
 
 
+def pmc_traffic(kernel_class, evals_per_launch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_fetch_write.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
+    this script; counters are in KB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    wide coalesced loads on gfx950). Counters cannot be read inside a timed run, so the per
+    workgroup (= per evaluated individual) figure is scaled to this run's launch size."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                        "r01_pmc_fetch_write.json")
+    if kernel_class != "indiv_eval(f+grad)" or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        pmc = json.load(fh)
+    key = "magma::indiv_eval_kernel<52>"
+    try:
+        kb = 2.0 * pmc["FETCH_SIZE"][key]["kb_per_workgroup_at_max"] \
+            + pmc["WRITE_SIZE"][key]["kb_per_workgroup_at_max"]
+    except KeyError:
+        return None
+    return kb * 1024.0 * evals_per_launch
+
+
 def cpu_baseline(cfg):
     """Oracle (NumPy/LAPACK port of the reference's operation sequence) on a bounded sample of
     the same workload, about 10-20 s of CPU work: the dense parts at the full grid size N
@@ -197,7 +218,8 @@ def main():
         if dom is not None:
             roof = {"kernel": dom, "bound": prof[dom]["bound"], "achieved": prof[dom]["achieved"],
                     "peak": prof[dom]["peak"], "unit": prof[dom]["unit"], "frac": prof[dom]["frac"],
-                    "traffic": None, "avg_launch_ms": prof[dom]["avg_ms"],
+                    "traffic": pmc_traffic(dom, eng.be.n_evals / ng), "traffic_unit": "bytes/launch",
+                    "avg_launch_ms": prof[dom]["avg_ms"],
                     "launches": prof[dom]["launches"],
                     "share_of_step_time": prof[dom]["share_of_step_time"]}
         e0 = eng.stats["theta0_evals"] / args.steps
@@ -222,7 +244,8 @@ def main():
             # E-step + e0 theta_0 evaluations + ei sweeps over M individuals + 2 monitorings
             # (each ~ one theta_0 f-evaluation + one f-sweep; priced at half an f+g evaluation)
             t_iter = (cb["t_estep_dense"] + cb["t_estep_per_indiv"] * Mloc
-                      + (e0 + 1.0) * cb["t_theta0_eval"] + (ei + 1.0) * cb["t_indiv_eval"] * Mloc)
+                      + (e0 + 1.0) * cb["t_theta0_eval"]
+                      + cb["t_indiv_eval"] * (eng.be.n_evals / args.steps + Mloc))
             try:
                 import threadpoolctl
                 cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) or 1

@@ -152,7 +152,9 @@ class HipBackend:
         import threading
         torch = self.torch
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            # high priority: the theta_0 chain is a long sequence of small dependent kernels that
+            # should not queue behind the wide per-individual launches it overlaps with
+            self._side = torch.cuda.Stream(device=self.dev, priority=-1)
         box = {}
 
         def work():

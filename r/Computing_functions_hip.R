@@ -5,8 +5,9 @@
 ##
 ## Usage: source the reference's scripts first, then this file (it overrides e_step,
 ## logL_GP_mod, gr_GP_mod, logL_GP_mod_common_hp, gr_GP_mod_common_hp, logL_monitoring,
-## posterior_mu); `training`, `m_step`, `full_algo`, `pred_gp`, `train_new_gp` keep the
-## reference's bodies and pick these up (opm keeps calling fn / gr per evaluation).
+## posterior_mu, and m_step for individual hyper-parameters); `training`, `full_algo`, `pred_gp`,
+## `train_new_gp` keep the reference's bodies and pick these up (opm keeps calling fn / gr per
+## evaluation for theta_0 and for common hyper-parameters).
 ## Only the SE kernel (`kernel` / `kernel_mu`) is accelerated; any other kernel falls back to
 ## the reference's R code, kept under the names *_ref.
 
@@ -114,4 +115,26 @@ logL_monitoring <- function(hp, db, kern_i, kern_0, mean_mu, cov_mu, m_0) {
   ri <- .Call("magmahip_indiv_eval", s$ptr, th, FALSE, 0L)
   if (r0[4] != 0 || any(ri[[3]] != 0)) return(logL_monitoring_ref(hp, db, kern_i, kern_0, mean_mu, cov_mu, m_0))
   -r0[1] - sum(ri[[1]])
+}
+
+## m_step (CF:397-437) with individual hyper-parameters: the M independent optim() calls of
+## CF:423-431 become ONE .Call (magma_indiv_mstep: batched lock-step L-BFGS-B in the library);
+## theta_0 keeps going through opm with the GPU fn / gr above. common_hp = TRUE and non-SE
+## kernels keep the reference's body.
+m_step_ref <- m_step
+m_step <- function(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp) {
+  if (common_hp || !(.hip_is_se(kern_0) && .hip_is_se(kern_i)))
+    return(m_step_ref(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp))
+  s <- .hip_get(db, mean$Timestamp)
+  th <- .hip_theta_mat(old_hp$theta_i, s$ids)
+  pen_diag <- mean(2 * th[3, ])                                              # CF:409
+  new_theta_0 <- opm(old_hp$theta_0, logL_GP_mod, gr_GP_mod, db = mean, mean = m_0, kern = kern_0,
+                     new_cov = cov, pen_diag = pen_diag, method = "L-BFGS-B",
+                     control = list(kkt = FALSE))[1, 1:2]
+  .Call("magmahip_set_posterior", s$ptr, mean$Output[order(mean$Timestamp)], cov)
+  r <- .Call("magmahip_indiv_mstep", s$ptr, th, 0L)
+  if (any(r[[4]] == 5)) return(m_step_ref(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp))
+  new_theta_i <- lapply(seq_along(s$ids), function(j) setNames(r[[1]][, j], names(old_hp$theta_i[[1]])))
+  names(new_theta_i) <- s$ids
+  list(theta_0 = new_theta_0, theta_i = new_theta_i)
 }

@@ -192,6 +192,37 @@ SEXP magmahip_indiv_eval(SEXP sx, SEXP theta_i, SEXP want_grad, SEXP mode) {
   return out;
 }
 
+/* m_step's individual part (CF:419-432): one L-BFGS-B problem per individual, all advanced in
+ * lock step by the library. theta_i: 3 x M start values. Returns list(par 3 x M, value M,
+ * counts M, convergence-status M). */
+SEXP magmahip_indiv_mstep(SEXP sx, SEXP theta_i, SEXP mode) {
+  session *s = get_sess(sx);
+  if (LENGTH(theta_i) != 3 * s->M) Rf_error("magmahip: theta_i must be 3 x M");
+  int *sel = NULL;
+  int rc = magma_dev_malloc((void **)&sel, sizeof(int) * (s->M > 0 ? s->M : 1));
+  SEXP par = PROTECT(allocMatrix(REALSXP, 3, s->M));
+  SEXP val = PROTECT(allocVector(REALSXP, s->M));
+  SEXP nfev = PROTECT(allocVector(INTSXP, s->M));
+  SEXP status = PROTECT(allocVector(INTSXP, s->M));
+  if (!rc)
+    rc = magma_indiv_mstep(asInteger(mode), s->M, s->nmax, s->off, s->t, s->y, s->idx, s->mean,
+                           s->cpack, REAL(theta_i), 5, 1e7, 0.0, 100, s->theta, sel, s->f, s->g,
+                           s->info, REAL(par), REAL(val), NULL, NULL, INTEGER(nfev),
+                           INTEGER(status), NULL, NULL, NULL);
+  if (sel) magma_dev_free(sel);
+  if (rc) {
+    UNPROTECT(4);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 4));
+  SET_VECTOR_ELT(out, 0, par);
+  SET_VECTOR_ELT(out, 1, val);
+  SET_VECTOR_ELT(out, 2, nfev);
+  SET_VECTOR_ELT(out, 3, status);
+  UNPROTECT(5);
+  return out;
+}
+
 /* logL_GP_mod + gr_GP_mod at theta_0: returns c(f, g1, g2, info). */
 SEXP magmahip_theta0_eval(SEXP sx, SEXP theta0, SEXP pen, SEXP m0, SEXP want_grad) {
   session *s = get_sess(sx);
@@ -216,6 +247,7 @@ static const R_CallMethodDef call_methods[] = {
     {"magmahip_e_step", (DL_FUNC)&magmahip_e_step, 5},
     {"magmahip_set_posterior", (DL_FUNC)&magmahip_set_posterior, 3},
     {"magmahip_indiv_eval", (DL_FUNC)&magmahip_indiv_eval, 4},
+    {"magmahip_indiv_mstep", (DL_FUNC)&magmahip_indiv_mstep, 3},
     {"magmahip_theta0_eval", (DL_FUNC)&magmahip_theta0_eval, 5},
     {NULL, NULL, 0}};
 

@@ -109,3 +109,57 @@ def test_oracle_training_reproduces_stored_hyperparameters(d):
     ref = hp_of("hp_FT", d)
     assert np.abs(res["hp"]["theta_0"] - ref["theta_0"]).max() < 1e-8
     assert max(np.abs(res["hp"]["theta_i"][i] - v).max() for i, v in ref["theta_i"].items()) < 1e-8
+
+
+def test_lbfgsb_compact_ask_tell_equals_full_size_ask_tell():
+    """The O(running problems) interface used by magma_indiv_mstep walks the same states as the
+    full-size one (host only: no GPU call)."""
+    import ctypes as C
+    from magma_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    B, d = 40, 3
+    x0 = rng.normal(0.0, 1.0, (B, d))
+    scale = rng.uniform(0.5, 30.0, (B, d))
+    ctr = rng.normal(0.0, 2.0, (B, d))
+
+    def fg(x, rows):  # separable quartic + quadratic, different conditioning per problem
+        z = x - ctr[rows]
+        f = np.sum(scale[rows] * z ** 2 + 0.1 * z ** 4, axis=1)
+        return f, 2 * scale[rows] * z + 0.4 * z ** 3
+
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    out = []
+    for compact in (False, True):
+        s = lib.magma_lbfgsb_create(B, d, vp(np.ascontiguousarray(x0)), 5, 1e7, 0.0, 100)
+        rounds = 0
+        while True:
+            na = C.c_int(0)
+            if compact:
+                sel = np.zeros(B, dtype=np.int32)
+                x = np.zeros((B, d))
+                lib.magma_lbfgsb_ask_compact(s, vp(sel), vp(x), C.byref(na))
+                if na.value == 0:
+                    break
+                rows = sel[:na.value]
+                f, g = fg(x[:na.value], rows)
+                lib.magma_lbfgsb_tell_compact(s, na.value, vp(sel), vp(np.ascontiguousarray(f)),
+                                              vp(np.ascontiguousarray(g)))
+            else:
+                act = np.zeros(B, dtype=np.uint8)
+                x = np.zeros((B, d))
+                lib.magma_lbfgsb_ask(s, vp(x), vp(act), C.byref(na))
+                if na.value == 0:
+                    break
+                f, g = fg(x, np.arange(B))
+                lib.magma_lbfgsb_tell(s, vp(np.ascontiguousarray(f)), vp(np.ascontiguousarray(g)))
+            rounds += 1
+            assert rounds < 5000
+        xr, fr = np.zeros((B, d)), np.zeros(B)
+        it, nf, stt = (np.zeros(B, dtype=np.int32) for _ in range(3))
+        lib.magma_lbfgsb_result(s, vp(xr), vp(fr), vp(it), vp(nf), vp(stt))
+        lib.magma_lbfgsb_destroy(s)
+        out.append((xr, fr, it, nf, stt, rounds))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][0] - ctr).max() < 1e-4
