@@ -178,6 +178,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    stats = dict(eng.stats)
+    n_evals = eng.be.n_evals
+    # the three rates behind an "EM iteration" (whose evaluation counts are data
+    # dependent), each timed alone after the timed region on the final hyper-parameters
+    def rate(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return reps / (time.perf_counter() - t1)
+    pen_e = float(np.mean(theta_i[:, 2]))
+    rates = {"e_step_per_s": rate(lambda: eng.e_step(theta0, theta_i, pen_e, 0.0)),
+             "theta0_f_and_grad_evals_per_s": rate(lambda: eng.f0(theta0, 2.0 * pen_e, True))}
+    if not common:
+        rates["indiv_sweeps_per_s"] = rate(
+            lambda: eng.be.indiv_eval(theta_i[eng.lo:eng.hi], True))
+
     prof = {}
     for pid, name in enumerate(PROF_NAMES):
         cnt, ms = C.c_int(0), C.c_double(0.0)
@@ -198,7 +217,7 @@ def main():
             "theta0_contract": ("mfma", 2.0 * N ** 3, True),
             "spd_inverse": ("mfma", 1.0 * N ** 3, False),  # composite: ~75 launches per call
             # 5 n^3 flops x the individuals actually evaluated per launch (active list)
-            "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * eng.be.n_evals / ng, True),
+            "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * n_evals / ng, True),
             "indiv_eval(f)": ("mfma", 1.0 * S3, True),
             "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n, True),
         }
@@ -218,12 +237,12 @@ def main():
         if dom is not None:
             roof = {"kernel": dom, "bound": prof[dom]["bound"], "achieved": prof[dom]["achieved"],
                     "peak": prof[dom]["peak"], "unit": prof[dom]["unit"], "frac": prof[dom]["frac"],
-                    "traffic": pmc_traffic(dom, eng.be.n_evals / ng), "traffic_unit": "bytes/launch",
+                    "traffic": pmc_traffic(dom, n_evals / ng), "traffic_unit": "bytes/launch",
                     "avg_launch_ms": prof[dom]["avg_ms"],
                     "launches": prof[dom]["launches"],
                     "share_of_step_time": prof[dom]["share_of_step_time"]}
-        e0 = eng.stats["theta0_evals"] / args.steps
-        ei = (eng.stats["common_evals"] if common else eng.stats["indiv_rounds"]) / args.steps
+        e0 = stats["theta0_evals"] / args.steps
+        ei = (stats["common_evals"] if common else stats["indiv_rounds"]) / args.steps
         out = {
             "metric": "EM iterations/sec (E+M) at M=10k tasks", "value": value,
             "unit": "EM it/s (10k-task units)", "n_gpus": world, "steps": args.steps,
@@ -235,7 +254,7 @@ def main():
                        "M_per_gpu": Mloc, "theta0_evals_per_step": e0,
                        "indiv_eval_rounds_per_step": ei, "parallelism": f"dp{world}",
                        "logLL_trace": lls},
-            "roofline": roof, "kernel_classes": prof,
+            "roofline": roof, "rates": rates, "kernel_classes": prof,
         }
         if not args.no_cpu_baseline and world == 1:
             t0c = time.time()
@@ -245,7 +264,7 @@ def main():
             # (each ~ one theta_0 f-evaluation + one f-sweep; priced at half an f+g evaluation)
             t_iter = (cb["t_estep_dense"] + cb["t_estep_per_indiv"] * Mloc
                       + (e0 + 1.0) * cb["t_theta0_eval"]
-                      + cb["t_indiv_eval"] * (eng.be.n_evals / args.steps + Mloc))
+                      + cb["t_indiv_eval"] * (n_evals / args.steps + Mloc))
             try:
                 import threadpoolctl
                 cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) or 1
