@@ -161,52 +161,40 @@ __device__ __forceinline__ double fast_rsqrt_d(double d) {
   return y;
 }
 
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t ld,
-                                                          int k, double* __restrict__ X,
-                                                          double* __restrict__ U,
-                                                          double* __restrict__ logdet,
-                                                          int* __restrict__ info) {
-  // The column loops run over 16 quads of 4 columns with the register window ROTATED after
-  // each quad (d[0] is always the quad being eliminated), so the body is a few KB that stays
-  // in the instruction cache (a fully unrolled 64-column body is ~70 KB of straight-line code
-  // and ran instruction-fetch bound). Each wavefront issues the whole column step on its own
-  // SIMD, so the per-column instruction count is what sets the time: the loop keeps only the
-  // rank-1 update; scaling by 1/L_jj, the log-det and the SPD check are vector passes after it.
-  __shared__ double Ls[128 * 65];    // rows >= 64 are only read into dead registers
-  __shared__ double colbuf[2][128];  // entries >= 64 likewise
-  __shared__ double piv[64];
-  __shared__ double invd[64];
+// Factor the 64 x 64 SPD diagonal block whose elements the workgroup holds as d[16] per thread
+// (thread map above) and emit X_kk = L_kk^-1, U_kk = L_kk^-T (the leaves of the triangular
+// inverse, and the operand that turns the block-row solve into an MFMA product), log-det and
+// info. LDS: Ls[128 * 65] (rows >= 64 are only read into dead registers), colbuf[2][128]
+// (entries >= 64 likewise), piv[64], invd[64].
+// The column loops run over 16 quads of 4 columns with the register window ROTATED after each
+// quad (d[0] is always the quad being eliminated), so the body is a few KB that stays in the
+// instruction cache (a fully unrolled 64-column body is ~70 KB of straight-line code and ran
+// instruction-fetch bound). Each wavefront issues the whole column step on its own SIMD, so the
+// per-column instruction count is what sets the time: the loop keeps only the rank-1 update;
+// scaling by 1/L_jj, the log-det and the SPD check are vector passes after it.
+__device__ __forceinline__ void potrf_diag_block(double (&d)[16], double* Ls, double* colbuf,
+                                                 double* piv, double* invd, int k, int64_t ld,
+                                                 double* __restrict__ X, double* __restrict__ U,
+                                                 double* __restrict__ logdet,
+                                                 int* __restrict__ info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = 16 * wave + (lane >> 2), ty = lane & 3;
-  const int w = blockIdx.x;
   const int ldi = (int)ld;  // block-local offsets fit 32 bits (64 columns of one block)
-  double* Akk = A + (int64_t)k * NB * (ld + 1);
-  double d[16];
+  double b[16];  // identity: X L^T = I yields L_kk^-1
 #pragma unroll
-  for (int q = 0; q < 16; ++q) d[q] = Akk[row + (4 * q + ty) * ldi];
-  // B block (A_ik, or the identity for workgroup 0) loaded up front: overlaps the factorisation
-  double b[16];
-  double* Aik = A + (int64_t)(k + w) * NB + (int64_t)k * NB * ld;
-  if (w == 0) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) b[q] = (4 * q + ty == row) ? 1.0 : 0.0;
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) b[q] = Aik[row + (4 * q + ty) * ldi];
-  }
+  for (int q = 0; q < 16; ++q) b[q] = (4 * q + ty == row) ? 1.0 : 0.0;
   if (tid < 128) {
-    colbuf[0][tid] = 0.0;
-    colbuf[1][tid] = 0.0;
+    colbuf[tid] = 0.0;
+    colbuf[128 + tid] = 0.0;
   }
   for (int e = tid; e < 64 * 65; e += 256) Ls[64 * 65 + e] = 0.0;
   __syncthreads();
-#ifndef MAGMA_DBG_SKIP_FACTOR
 #pragma unroll 1
   for (int q0 = 0; q0 < 16; ++q0) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = 4 * q0 + jj;
-      double* cb = colbuf[jj & 1];
+      double* cb = colbuf + 128 * (jj & 1);
       if (ty == jj) {
         cb[row] = d[0];
         Ls[row * 65 + j] = d[0];  // unscaled column j (rows >= j are final); scaled below
@@ -229,29 +217,23 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     for (int q = 0; q < 15; ++q) d[q] = d[q + 1];
     d[15] = 0.0;
   }
-#endif
   __syncthreads();
   // pivots -> 1/L_jj, SPD check and log-det (first wavefront); then L = columns * 1/L_jj
   if (wave == 0) {
     const double pj = piv[lane];
     const bool ok = (pj > 0.0) && (pj < 1.7e308);
     invd[lane] = fast_rsqrt_d(ok ? pj : 1.0);
-    if (w == 0) {
-      const unsigned long long badmask = __ballot(!ok);
-      int e;
-      const double m = frexp(ok ? pj : 1.0, &e);
-      double lg = log(m) + (double)e * 0.69314718055994530941723212145818;
-      lg = wave_sum(lg);
-      if (lane == 0) {
-        logdet[0] += lg;
-        if (badmask != 0ull && info[0] == 0) info[0] = k * NB + __ffsll((long long)badmask);
-      }
+    const unsigned long long badmask = __ballot(!ok);
+    int e;
+    const double m = frexp(ok ? pj : 1.0, &e);
+    double lg = log(m) + (double)e * 0.69314718055994530941723212145818;
+    lg = wave_sum(lg);
+    if (lane == 0) {
+      logdet[0] += lg;  // one workgroup per step, steps are stream ordered
+      if (badmask != 0ull && info[0] == 0) info[0] = k * NB + __ffsll((long long)badmask);
     }
   }
   __syncthreads();
-  // L_kk is NOT written back over A_kk: the other workgroups of this launch re-factor A_kk
-  // from global memory and may start after this point; nothing downstream reads L_kk (the
-  // triangular inverse starts from U_kk / X_kk below).
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int c = 4 * q + ty;
@@ -259,11 +241,10 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     Ls[row * 65 + c] = (row >= c) ? v : 0.0;
   }
   __syncthreads();
-  // X L^T = B, column by column; rows are independent and each row sits in one quad, so this
+  // X L^T = I, column by column; rows are independent and each row sits in one quad, so this
   // phase needs no barrier. b[0] is final once its quad is done and is stored right away.
   double* Ukk = U + (int64_t)k * NB * (ld + 1);
   double* Xkk = X + (int64_t)k * NB * (ld + 1);
-#ifndef MAGMA_DBG_SKIP_TRSM
 #pragma unroll 1
   for (int q0 = 0; q0 < 16; ++q0) {
     const double* lq = Ls + (4 * q0 + ty) * 65 + 4 * q0;  // L[4 q0 + ty][4 q0]
@@ -278,34 +259,89 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
       for (int q = 1; q < 16; ++q) b[q] = fma(-x, lq[q * 4 * 65 + jj], b[q]);
     }
     const int c = 4 * q0 + ty;
-    if (w == 0) {
-      Ukk[row + c * ldi] = b[0];
-      Xkk[c + row * ldi] = b[0];
-    } else {
-      Aik[row + c * ldi] = b[0];
-    }
+    Ukk[row + c * ldi] = b[0];
+    Xkk[c + row * ldi] = b[0];
 #pragma unroll
     for (int q = 0; q < 15; ++q) b[q] = b[q + 1];
     b[15] = 0.0;
   }
-#endif
+}
+
+// Step 0: the first diagonal block (one workgroup).
+__global__ __launch_bounds__(256) void potrf_diag0_kernel(const double* __restrict__ A, int64_t ld,
+                                                          double* __restrict__ X,
+                                                          double* __restrict__ U,
+                                                          double* __restrict__ logdet,
+                                                          int* __restrict__ info) {
+  __shared__ double Ls[128 * 65];
+  __shared__ double colbuf[2 * 128];
+  __shared__ double piv[64];
+  __shared__ double invd[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = 16 * wave + (lane >> 2), ty = lane & 3;
+  double d[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[q] = A[row + (int64_t)(4 * q + ty) * ld];
+  potrf_diag_block(d, Ls, colbuf, piv, invd, 0, ld, X, U, logdet, info);
+}
+
+// Block-row solve of step k as an MFMA product: L_ik = A_ik L_kk^-T = A_ik X_kk^T, in place.
+__global__ __launch_bounds__(256) void trsm_gemm_kernel(double* __restrict__ A, int64_t ld, int k,
+                                                        const double* __restrict__ X) {
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  const int i = k + 1 + blockIdx.x;
+  double* Aik = A + (int64_t)i * NB + (int64_t)k * NB * ld;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(Aik, ld, X + (int64_t)k * NB * (ld + 1), ld, 4, acc, As, Bs);
+  __syncthreads();  // every wavefront has consumed A_ik before it is overwritten
+  tile_foreach(acc, [&](int m, int n, double v) { Aik[m + (int64_t)n * ld] = v; });
 }
 
 // ------------------------------------------------------------------ trailing update
-// A_ij -= L_ik L_jk^T for k < j <= i.
+// A_ij -= L_ik L_jk^T for k < j <= i. The workgroup of tile (k+1, k+1) -- block 0, dispatched
+// first -- goes on to factor that tile and emit X / U of step k+1 (potrf_diag_block) while the
+// other workgroups finish the update: the serial part of the next step hides behind this one.
 __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A, int64_t ld,
-                                                          int k) {
-  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
-  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
-  const int bi = blockIdx.x, bj = blockIdx.y;
-  if (bj > bi) return;
+                                                          int k, int nt, double* __restrict__ X,
+                                                          double* __restrict__ U,
+                                                          double* __restrict__ logdet,
+                                                          int* __restrict__ info) {
+  __shared__ double Ls[128 * 65];
+  __shared__ double colbuf[2 * 128];
+  __shared__ double piv[64];
+  __shared__ double invd[64];
+  double* As = Ls + 64 * 65;  // operand slabs in the half of Ls that is dead space until
+  double* Bs = As + 16 * TLD;  // potrf_diag_block zeroes it
+  // lower-triangle tile index -> (bi, bj), bj <= bi; tile 0 = (0, 0) = block (k+1, k+1)
+  const int p = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (bi * (bi + 1) / 2 > p) --bi;
+  while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
+  const int bj = p - bi * (bi + 1) / 2;
   const int i = k + 1 + bi, j = k + 1 + bj;
   TileAcc acc;
   tile_zero(acc);
   tile_gemm_nt(A + (int64_t)i * NB + (int64_t)k * NB * ld, ld,
                A + (int64_t)j * NB + (int64_t)k * NB * ld, ld, 4, acc, As, Bs);
   double* C = A + (int64_t)i * NB + (int64_t)j * NB * ld;
-  tile_foreach(acc, [&](int m, int n, double v) { C[m + (int64_t)n * ld] -= v; });
+  if (p != 0) {
+    tile_foreach(acc, [&](int m, int n, double v) { C[m + (int64_t)n * ld] -= v; });
+    return;
+  }
+  // diagonal block of the next step: updated tile -> LDS -> the factorisation's thread map
+  // (not written back: nothing reads L_kk or A_kk afterwards)
+  __syncthreads();
+  tile_foreach(acc, [&](int m, int n, double v) { Ls[m * 65 + n] = C[m + (int64_t)n * ld] - v; });
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = 16 * wave + (lane >> 2), ty = lane & 3;
+  double d[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[q] = Ls[row * 65 + 4 * q + ty];
+  __syncthreads();
+  potrf_diag_block(d, Ls, colbuf, piv, invd, k + 1, ld, X, U, logdet, info);
 }
 
 // ------------------------------------------------------------------ triangular inverse
@@ -604,13 +640,12 @@ int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* wor
   double* W = work + 2 * (size_t)Np * Np;
   MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
   MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-  for (int k = 0; k < nt; ++k) {
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3(nt - k), dim3(256), 0, st, A, ld, k, X, U, logdet,
-                       info);
-    if (k + 1 < nt) {
-      const int rem = nt - k - 1;
-      hipLaunchKernelGGL(syrk_update_kernel, dim3(rem, rem), dim3(256), 0, st, A, ld, k);
-    }
+  hipLaunchKernelGGL(potrf_diag0_kernel, dim3(1), dim3(256), 0, st, A, ld, X, U, logdet, info);
+  for (int k = 0; k + 1 < nt; ++k) {
+    const int rem = nt - k - 1;
+    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(rem), dim3(256), 0, st, A, ld, k, X);
+    hipLaunchKernelGGL(syrk_update_kernel, dim3(rem * (rem + 1) / 2), dim3(256), 0, st, A, ld, k, nt,
+                       X, U, logdet, info);
   }
   int depth = 0;
   while ((1 << depth) < nt) ++depth;
