@@ -12,10 +12,10 @@
 // 121-138; solve(new_inv) CF:387; logL_GP_mod / gr_GP_mod at theta_0 (CF:181-201, 304-332).
 #include "common.h"
 #include "kernels.h"
+#include "mfma_sweep.h"
 
 namespace magma {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int TLD = 80;  // LDS row length (doubles) of a staged 16 x 64 operand slab
 constexpr int NB = 64;
 
@@ -267,12 +267,55 @@ __device__ __forceinline__ void potrf_diag_block(double (&d)[16], double* Ls, do
   }
 }
 
+// The same job on the matrix cores, by the workgroup's first wavefront: blocked Cholesky of the
+// staged tile S (S[m * 65 + n], lower triangle valid) with the identity carried along
+// (mfma_chol_inverse64): 200 MFMAs + 16 4x4 factorisations instead of 64 barrier-separated
+// column steps and a 64-step triangular solve.
+__device__ __forceinline__ void potrf_diag_block_mfma(const double* S, double* Pn, double* Bn,
+                                                      int k, int64_t ld, double* __restrict__ X,
+                                                      double* __restrict__ U,
+                                                      double* __restrict__ logdet,
+                                                      int* __restrict__ info) {
+  const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
+  v4d A[4][4], B[4][4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
+        A[it][jt][v] = (r >= c) ? S[r * 65 + c] : S[c * 65 + r];
+      }
+  double pm = 1.0;
+  int pe = 0, bad = 0;
+  mfma_chol_inverse64(A, B, Pn, Bn, l, g, pm, pe, bad);
+  double* Ukk = U + (int64_t)k * NB * (ld + 1);
+  double* Xkk = X + (int64_t)k * NB * (ld + 1);
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
+        const double x = (jt <= it) ? B[it][jt][v] : 0.0;  // X = L^-1 is lower triangular
+        Xkk[r + (int64_t)c * ld] = x;
+        Ukk[c + (int64_t)r * ld] = x;
+      }
+  if (lane == 0) {
+    logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
+    if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
+  }
+}
+
 // Step 0: the first diagonal block (one workgroup).
 __global__ __launch_bounds__(256) void potrf_diag0_kernel(const double* __restrict__ A, int64_t ld,
                                                           double* __restrict__ X,
                                                           double* __restrict__ U,
                                                           double* __restrict__ logdet,
                                                           int* __restrict__ info) {
+#ifdef MAGMA_DIAG_VECTOR
   __shared__ double Ls[128 * 65];
   __shared__ double colbuf[2 * 128];
   __shared__ double piv[64];
@@ -283,6 +326,16 @@ __global__ __launch_bounds__(256) void potrf_diag0_kernel(const double* __restri
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = A[row + (int64_t)(4 * q + ty) * ld];
   potrf_diag_block(d, Ls, colbuf, piv, invd, 0, ld, X, U, logdet, info);
+#else
+  __shared__ double Ls[64 * 65];
+  __shared__ __attribute__((aligned(16))) double Pn[512];
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int m = e & 63, n = e >> 6;
+    Ls[m * 65 + n] = A[m + (int64_t)n * ld];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) potrf_diag_block_mfma(Ls, Pn, Pn + 256, 0, ld, X, U, logdet, info);
+#endif
 }
 
 // Block-row solve of step k as an MFMA product: L_ik = A_ik L_kk^-T = A_ik X_kk^T, in place.
@@ -308,12 +361,20 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
                                                           double* __restrict__ U,
                                                           double* __restrict__ logdet,
                                                           int* __restrict__ info) {
+#ifdef MAGMA_DIAG_VECTOR
   __shared__ double Ls[128 * 65];
   __shared__ double colbuf[2 * 128];
   __shared__ double piv[64];
   __shared__ double invd[64];
   double* As = Ls + 64 * 65;  // operand slabs in the half of Ls that is dead space until
   double* Bs = As + 16 * TLD;  // potrf_diag_block zeroes it
+#else
+  __shared__ __attribute__((aligned(16))) double Ls[64 * 65];  // staged diagonal tile; its head
+  __shared__ __attribute__((aligned(16))) double Pn[512];      // doubles as the operand slabs
+  static_assert(2 * 16 * TLD <= 64 * 65, "operand slabs must fit the staging tile");
+  double* As = Ls;
+  double* Bs = As + 16 * TLD;
+#endif
   // lower-triangle tile index -> (bi, bj), bj <= bi; tile 0 = (0, 0) = block (k+1, k+1)
   const int p = blockIdx.x;
   int bi = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
@@ -335,6 +396,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
   __syncthreads();
   tile_foreach(acc, [&](int m, int n, double v) { Ls[m * 65 + n] = C[m + (int64_t)n * ld] - v; });
   __syncthreads();
+#ifdef MAGMA_DIAG_VECTOR
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = 16 * wave + (lane >> 2), ty = lane & 3;
   double d[16];
@@ -342,6 +404,9 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
   for (int q = 0; q < 16; ++q) d[q] = Ls[row * 65 + 4 * q + ty];
   __syncthreads();
   potrf_diag_block(d, Ls, colbuf, piv, invd, k + 1, ld, X, U, logdet, info);
+#else
+  if (threadIdx.x < 64) potrf_diag_block_mfma(Ls, Pn, Pn + 256, k + 1, ld, X, U, logdet, info);
+#endif
 }
 
 // ------------------------------------------------------------------ triangular inverse

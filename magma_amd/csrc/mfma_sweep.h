@@ -160,3 +160,150 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
 }
 
 }  // namespace magma
+
+namespace magma {
+
+// ------------------------------------------------------------------ blocked Cholesky + L^-1
+// M = L4^-1 (lower triangular, 4 x 4) of the Cholesky factor of the SPD block p (lower triangle
+// read), and the four pivots d_k = L_kk^2 (the same pivots a column-by-column Cholesky sees:
+// log-det and SPD test). LDL' first, then the unit factor's inverse scaled by 1/sqrt(d).
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  return y;
+}
+
+__device__ __forceinline__ void chol4_inverse(const double (&p)[4][4], double (&M)[4][4],
+                                              double (&piv)[4], int& bad) {
+  bad = 0;
+  auto chk = [&](double d, int k) {
+    const bool ok = (d > 0.0) && (d < 1.7e308);
+    bad = (!ok && bad == 0) ? k + 1 : bad;
+  };
+  const double d0 = p[0][0];
+  chk(d0, 0);
+  const double r0 = fast_rcp(d0);
+  const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
+  const double d1 = fma(-l10, p[1][0], p[1][1]);
+  const double p21 = fma(-l20, p[1][0], p[2][1]);
+  const double p31 = fma(-l30, p[1][0], p[3][1]);
+  double p22 = fma(-l20, p[2][0], p[2][2]);
+  double p32 = fma(-l30, p[2][0], p[3][2]);
+  double p33 = fma(-l30, p[3][0], p[3][3]);
+  chk(d1, 1);
+  const double r1 = fast_rcp(d1);
+  const double l21 = p21 * r1, l31 = p31 * r1;
+  p22 = fma(-l21, p21, p22);
+  p32 = fma(-l31, p21, p32);
+  p33 = fma(-l31, p31, p33);
+  const double d2 = p22;
+  chk(d2, 2);
+  const double r2 = fast_rcp(d2);
+  const double l32 = p32 * r2;
+  const double d3 = fma(-l32, p32, p33);
+  chk(d3, 3);
+  piv[0] = d0; piv[1] = d1; piv[2] = d2; piv[3] = d3;
+  const double m10 = -l10, m21 = -l21, m32 = -l32;
+  const double m20 = -fma(l21, m10, l20);
+  const double m31 = -fma(l32, m21, l31);
+  const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+  const double s0 = fast_rsqrt(d0), s1 = fast_rsqrt(d1), s2 = fast_rsqrt(d2), s3 = fast_rsqrt(d3);
+  M[0][0] = s0;       M[0][1] = 0.0;      M[0][2] = 0.0;      M[0][3] = 0.0;
+  M[1][0] = s1 * m10; M[1][1] = s1;       M[1][2] = 0.0;      M[1][3] = 0.0;
+  M[2][0] = s2 * m20; M[2][1] = s2 * m21; M[2][2] = s2;       M[2][3] = 0.0;
+  M[3][0] = s3 * m30; M[3][1] = s3 * m31; M[3][2] = s3 * m32; M[3][3] = s3;
+}
+
+// One wavefront: right-looking Cholesky of the 64 x 64 SPD matrix A (accumulator layout, both
+// triangles) in blocks of 4 columns, applied at the same time to B = I, which ends as X = L^-1
+// (lower triangular, exact zeros above the diagonal). Block J (rows/columns 4b..4b+3):
+//   M = L_JJ^-1 (chol4_inverse of A[J,J], every lane redundantly);
+//   panel  Lp[i][g] = sum_h A[i][4b+h] M[g][h]  (rows i >= 4b; A's rows J are already in
+//          A-fragment layout by symmetry, the 4 x 4 product needs the other lane groups' values:
+//          through LDS);
+//   A -= Lp Lp^T on the tiles at or below/right of J (one MFMA per tile, Lp is both fragments);
+//   X[J,:] = M B[J,:] (same LDS exchange), B -= Lp X[J,:] on the rows below, X[J,:] stored
+//          over B[J,:].
+// 120 + 80 MFMAs in all. A is destroyed. pm, pe, info as in mfma_sweep. Pn, Bn: 256 doubles of
+// LDS each, owned by this wavefront.
+__device__ __forceinline__ void mfma_chol_inverse64(v4d (&A)[4][4], v4d (&B)[4][4], double* Pn,
+                                                    double* Bn, int l, int g, double& pm,
+                                                    int& pe, int& info) {
+  double gm[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    gm[h] = (g == h) ? 1.0 : 0.0;
+    asm volatile("" : "+v"(gm[h]));
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) B[it][jt][v] = (it == jt && g + 4 * v == l) ? 1.0 : 0.0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int it0 = b >> 2, v0 = b & 3;
+#pragma unroll
+    for (int jt = it0; jt < 4; ++jt) Pn[(16 * jt + l) * 4 + g] = A[it0][jt][v0];
+#pragma unroll
+    for (int jt = 0; jt <= it0; ++jt) Bn[(16 * jt + l) * 4 + g] = B[it0][jt][v0];
+    __builtin_amdgcn_wave_barrier();
+    double P4[4][4], M[4][4], piv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4 + 2]);
+      P4[r][0] = lo.x; P4[r][1] = lo.y; P4[r][2] = hi.x; P4[r][3] = hi.y;
+    }
+    int bad;
+    chol4_inverse(P4, M, piv, bad);
+    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int e;
+      pm *= frexp(piv[k], &e);
+      pe += e;
+    }
+    if ((b & 7) == 7) {
+      int e;
+      pm = frexp(pm, &e);
+      pe += e;
+    }
+    asm volatile("" : "+v"(pm), "+v"(pe));
+    // row g of M for this lane (0/1 weights: exact, and no divergent select chains)
+    double mr[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      mr[h] = fma(gm[3], M[3][h], fma(gm[2], M[2][h], fma(gm[1], M[1][h], gm[0] * M[0][h])));
+    double lp[4], xr[4];
+#pragma unroll
+    for (int it = it0; it < 4; ++it) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4 + 2]);
+      const double v = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
+      lp[it] = (it > it0 || l >= 4 * v0) ? v : 0.0;  // rows above the block are finished
+    }
+#pragma unroll
+    for (int jt = 0; jt <= it0; ++jt) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4 + 2]);
+      xr[jt] = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
+    }
+    __builtin_amdgcn_wave_barrier();  // Pn / Bn are rewritten by the next block
+#pragma unroll
+    for (int it = it0; it < 4; ++it) {
+#pragma unroll
+      for (int jt = it0; jt < 4; ++jt)
+        A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], lp[jt], A[it][jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt <= it0; ++jt)
+        B[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], xr[jt], B[it][jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jt = 0; jt <= it0; ++jt) B[it0][jt][v0] = xr[jt];
+  }
+}
+
+}  // namespace magma
