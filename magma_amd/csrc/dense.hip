@@ -267,45 +267,54 @@ __device__ __forceinline__ void potrf_diag_block(double (&d)[16], double* Ls, do
   }
 }
 
-// The same job on the matrix cores, by the workgroup's first wavefront: blocked Cholesky of the
-// staged tile S (S[m * 65 + n], lower triangle valid) with the identity carried along
-// (mfma_chol_inverse64): 200 MFMAs + 16 4x4 factorisations instead of 64 barrier-separated
-// column steps and a 64-step triangular solve.
-__device__ __forceinline__ void potrf_diag_block_mfma(const double* S, double* Pn, double* Bn,
+// The same job on the matrix cores, by two wavefronts of the (256-thread) workgroup: blocked
+// Cholesky of the staged tile S (S[m * 65 + n], lower triangle valid) in wavefront 0, the
+// identity carried along in wavefront 1 (chol64_factor / chol64_solve): 200 MFMAs + 16 4x4
+// factorisations instead of 64 barrier-separated column steps and a 64-step triangular solve.
+// Called by ALL wavefronts of the workgroup. LDS: Pn[512] (Pn, Bn), Xch[1024].
+__device__ __forceinline__ void potrf_diag_block_mfma(const double* S, double* Pn, double* Xch,
                                                       int k, int64_t ld, double* __restrict__ X,
                                                       double* __restrict__ U,
                                                       double* __restrict__ logdet,
                                                       int* __restrict__ info) {
-  const int lane = threadIdx.x, l = lane & 15, g = lane >> 4;
-  v4d A[4][4], B[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = lane & 15, g = lane >> 4;
+  if (wave == 0) {
+    v4d A[4][4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
-        A[it][jt][v] = (r >= c) ? S[r * 65 + c] : S[c * 65 + r];
-      }
-  double pm = 1.0;
-  int pe = 0, bad = 0;
-  mfma_chol_inverse64(A, B, Pn, Bn, l, g, pm, pe, bad);
-  double* Ukk = U + (int64_t)k * NB * (ld + 1);
-  double* Xkk = X + (int64_t)k * NB * (ld + 1);
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
+          A[it][jt][v] = (r >= c) ? S[r * 65 + c] : S[c * 65 + r];
+        }
+    double pm = 1.0;
+    int pe = 0, bad = 0;
+    chol64_factor(A, Pn, Xch, lane, pm, pe, bad);
+    if (lane == 0) {
+      logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
+      if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
+    }
+  } else if (wave == 1) {
+    v4d B[4][4];
+    chol64_solve(B, Pn + 256, Xch, lane);
+    double* Ukk = U + (int64_t)k * NB * (ld + 1);
+    double* Xkk = X + (int64_t)k * NB * (ld + 1);
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
-        const double x = (jt <= it) ? B[it][jt][v] : 0.0;  // X = L^-1 is lower triangular
-        Xkk[r + (int64_t)c * ld] = x;
-        Ukk[c + (int64_t)r * ld] = x;
-      }
-  if (lane == 0) {
-    logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
-    if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
+          const double x = (jt <= it) ? B[it][jt][v] : 0.0;  // X = L^-1 is lower triangular
+          Xkk[r + (int64_t)c * ld] = x;
+          Ukk[c + (int64_t)r * ld] = x;
+        }
+  } else {
+    chol64_idle();
   }
 }
 
@@ -329,12 +338,13 @@ __global__ __launch_bounds__(256) void potrf_diag0_kernel(const double* __restri
 #else
   __shared__ double Ls[64 * 65];
   __shared__ __attribute__((aligned(16))) double Pn[512];
+  __shared__ __attribute__((aligned(16))) double Xch[1024];
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int m = e & 63, n = e >> 6;
     Ls[m * 65 + n] = A[m + (int64_t)n * ld];
   }
   __syncthreads();
-  if (threadIdx.x < 64) potrf_diag_block_mfma(Ls, Pn, Pn + 256, 0, ld, X, U, logdet, info);
+  potrf_diag_block_mfma(Ls, Pn, Xch, 0, ld, X, U, logdet, info);
 #endif
 }
 
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
 #else
   __shared__ __attribute__((aligned(16))) double Ls[64 * 65];  // staged diagonal tile; its head
   __shared__ __attribute__((aligned(16))) double Pn[512];      // doubles as the operand slabs
+  __shared__ __attribute__((aligned(16))) double Xch[1024];
   static_assert(2 * 16 * TLD <= 64 * 65, "operand slabs must fit the staging tile");
   double* As = Ls;
   double* Bs = As + 16 * TLD;
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
   __syncthreads();
   potrf_diag_block(d, Ls, colbuf, piv, invd, k + 1, ld, X, U, logdet, info);
 #else
-  if (threadIdx.x < 64) potrf_diag_block_mfma(Ls, Pn, Pn + 256, k + 1, ld, X, U, logdet, info);
+  potrf_diag_block_mfma(Ls, Pn, Xch, k + 1, ld, X, U, logdet, info);
 #endif
 }
 

@@ -215,21 +215,26 @@ __device__ __forceinline__ void chol4_inverse(const double (&p)[4][4], double (&
   M[3][0] = s3 * m30; M[3][1] = s3 * m31; M[3][2] = s3 * m32; M[3][3] = s3;
 }
 
-// One wavefront: right-looking Cholesky of the 64 x 64 SPD matrix A (accumulator layout, both
-// triangles) in blocks of 4 columns, applied at the same time to B = I, which ends as X = L^-1
-// (lower triangular, exact zeros above the diagonal). Block J (rows/columns 4b..4b+3):
-//   M = L_JJ^-1 (chol4_inverse of A[J,J], every lane redundantly);
-//   panel  Lp[i][g] = sum_h A[i][4b+h] M[g][h]  (rows i >= 4b; A's rows J are already in
-//          A-fragment layout by symmetry, the 4 x 4 product needs the other lane groups' values:
-//          through LDS);
-//   A -= Lp Lp^T on the tiles at or below/right of J (one MFMA per tile, Lp is both fragments);
-//   X[J,:] = M B[J,:] (same LDS exchange), B -= Lp X[J,:] on the rows below, X[J,:] stored
-//          over B[J,:].
-// 120 + 80 MFMAs in all. A is destroyed. pm, pe, info as in mfma_sweep. Pn, Bn: 256 doubles of
-// LDS each, owned by this wavefront.
-__device__ __forceinline__ void mfma_chol_inverse64(v4d (&A)[4][4], v4d (&B)[4][4], double* Pn,
-                                                    double* Bn, int l, int g, double& pm,
-                                                    int& pe, int& info) {
+// Two wavefronts of one workgroup: right-looking Cholesky of the 64 x 64 SPD matrix A
+// (accumulator layout, both triangles) in blocks of 4 columns, applied at the same time to
+// B = I, which ends as X = L^-1 (lower triangular, exact zeros above the diagonal).
+// Block J (rows/columns 4b..4b+3):
+//   FACTOR wavefront (owns A):
+//     M = L_JJ^-1 (chol4_inverse of A[J,J], every lane redundantly);
+//     panel  Lp[i][g] = sum_h A[i][4b+h] M[g][h]  (rows i >= 4b; A's rows J are already in
+//            A-fragment layout by symmetry, the 4 x 4 product needs the other lane groups'
+//            values: through LDS);
+//     A -= Lp Lp^T on the tiles at or below/right of J (one MFMA per tile, Lp is both fragments);
+//     Lp and this lane's row of M published to the SOLVE wavefront (slot b & 1 of Xch), barrier.
+//   SOLVE wavefront (owns B), one block behind:
+//     X[J,:] = M B[J,:] (same kind of LDS exchange), B -= Lp X[J,:] on the rows below, X[J,:]
+//            stored over B[J,:].
+// 120 + 80 MFMAs in all; the two chains overlap, so the workgroup's time is the FACTOR chain's.
+// Every wavefront of the workgroup must execute the 16 barriers (chol64_idle for the others).
+// Pn, Bn: 256 doubles of LDS each (private to FACTOR / SOLVE); Xch: 2 x 512 doubles.
+__device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane,
+                                              double& pm, int& pe, int& info) {
+  const int l = lane & 15, g = lane >> 4;
   double gm[4];
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
@@ -237,18 +242,10 @@ __device__ __forceinline__ void mfma_chol_inverse64(v4d (&A)[4][4], v4d (&B)[4][
     asm volatile("" : "+v"(gm[h]));
   }
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) B[it][jt][v] = (it == jt && g + 4 * v == l) ? 1.0 : 0.0;
-#pragma unroll
   for (int b = 0; b < 16; ++b) {
     const int it0 = b >> 2, v0 = b & 3;
 #pragma unroll
     for (int jt = it0; jt < 4; ++jt) Pn[(16 * jt + l) * 4 + g] = A[it0][jt][v0];
-#pragma unroll
-    for (int jt = 0; jt <= it0; ++jt) Bn[(16 * jt + l) * 4 + g] = B[it0][jt][v0];
     __builtin_amdgcn_wave_barrier();
     double P4[4][4], M[4][4], piv[4];
 #pragma unroll
@@ -277,33 +274,73 @@ __device__ __forceinline__ void mfma_chol_inverse64(v4d (&A)[4][4], v4d (&B)[4][
 #pragma unroll
     for (int h = 0; h < 4; ++h)
       mr[h] = fma(gm[3], M[3][h], fma(gm[2], M[2][h], fma(gm[1], M[1][h], gm[0] * M[0][h])));
-    double lp[4], xr[4];
+    double lp[4];
 #pragma unroll
-    for (int it = it0; it < 4; ++it) {
+    for (int it = 0; it < 4; ++it) {
+      if (it < it0) {
+        lp[it] = 0.0;
+        continue;
+      }
       const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4 + 2]);
       const double v = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
       lp[it] = (it > it0 || l >= 4 * v0) ? v : 0.0;  // rows above the block are finished
     }
+    double* slot = Xch + 512 * (b & 1);
+#pragma unroll
+    for (int it = it0; it < 4; ++it) slot[it * 64 + lane] = lp[it];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) slot[(4 + h) * 64 + lane] = mr[h];
+    __syncthreads();  // barrier b: block b published; the slot of block b-2 may be reused
+#pragma unroll
+    for (int it = it0; it < 4; ++it)
+#pragma unroll
+      for (int jt = it0; jt < 4; ++jt)
+        A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], lp[jt], A[it][jt], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const double* Xch,
+                                             int lane) {
+  const int l = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) B[it][jt][v] = (it == jt && g + 4 * v == l) ? 1.0 : 0.0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int it0 = b >> 2, v0 = b & 3;
+#pragma unroll
+    for (int jt = 0; jt <= it0; ++jt) Bn[(16 * jt + l) * 4 + g] = B[it0][jt][v0];
+    __syncthreads();  // barrier b
+    const double* slot = Xch + 512 * (b & 1);
+    double mr[4], lp[4], xr[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) mr[h] = slot[(4 + h) * 64 + lane];
+#pragma unroll
+    for (int it = it0; it < 4; ++it) lp[it] = slot[it * 64 + lane];
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) {
       const double2 lo = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4 + 2]);
       xr[jt] = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
     }
-    __builtin_amdgcn_wave_barrier();  // Pn / Bn are rewritten by the next block
+    __builtin_amdgcn_wave_barrier();  // Bn is rewritten by the next block
 #pragma unroll
-    for (int it = it0; it < 4; ++it) {
-#pragma unroll
-      for (int jt = it0; jt < 4; ++jt)
-        A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], lp[jt], A[it][jt], 0, 0, 0);
+    for (int it = it0; it < 4; ++it)
 #pragma unroll
       for (int jt = 0; jt <= it0; ++jt)
         B[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], xr[jt], B[it][jt], 0, 0, 0);
-    }
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) B[it0][jt][v0] = xr[jt];
   }
+}
+
+__device__ __forceinline__ void chol64_idle() {
+#pragma unroll 1
+  for (int b = 0; b < 16; ++b) __syncthreads();
 }
 
 }  // namespace magma
