@@ -41,7 +41,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X vendor figure; dense, no sp
 PEAK_HBM_GBS = 8000.0
 PROF_NAMES = ["gemm_nt(T=Kinv*C)", "theta0_contract", "spd_inverse", "indiv_eval(f+grad)",
               "indiv_eval(f)", "estep_scatter", "se_cov_grid", "se_cov_batched", "se_inv_batched",
-              "indiv_gather_cov"]
+              "indiv_gather_cov", "indiv_mstep(resident)"]
 
 
 def pmc_traffic(kernel_class, evals_per_launch):

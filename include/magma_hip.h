@@ -135,6 +135,16 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
                       double* d_theta, int* d_sel, double* d_f, double* d_g, int* d_info,
                       double* h_theta_out, double* h_f_out, double* h_f_x0, int* h_iters,
                       int* h_nfev, int* h_status, int* h_rounds, int64_t* h_nevals, void* stream);
+/* The same M problems solved without leaving the GPU: the wavefront that evaluates an
+ * individual also steps its L-BFGS-B (the code magma_lbfgsb_* runs on the host, compiled for
+ * the device), evaluation after evaluation, until that problem stops; no round trips, no lock
+ * step. All pointers are DEVICE memory: theta0[3M] in; theta_out[3M], f_out[M], f_x0[M],
+ * iters[M], nfev[M], status[M] out (same meaning as above). m <= 5. Asynchronous on stream. */
+int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,
+                               const double* y, const int* idx, const double* mean,
+                               const double* cpack, const double* theta0, int m, double factr,
+                               double pgtol, int maxit, double* theta_out, double* f_out,
+                               double* f_x0, int* iters, int* nfev, int* status, void* stream);
 /* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
  * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
  * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */

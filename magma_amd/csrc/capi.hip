@@ -57,7 +57,7 @@ static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 // roofline figures): off by default, no cost when off.
 enum ProfId { PROF_GEMM = 0, PROF_CONTRACT, PROF_SPD_INVERSE, PROF_INDIV_EVAL, PROF_INDIV_F,
               PROF_SCATTER, PROF_COV_GRID, PROF_COV_BATCHED, PROF_INV_BATCHED, PROF_GATHER_COV,
-              PROF_N };
+              PROF_INDIV_MSTEP, PROF_N };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_N];
@@ -308,6 +308,19 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
   if (h_rounds) *h_rounds = rounds;
   if (h_nevals) *h_nevals = nevals;
   return rc;
+}
+
+int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,
+                               const double* y, const int* idx, const double* mean,
+                               const double* cpack, const double* theta0, int m, double factr,
+                               double pgtol, int maxit, double* theta_out, double* f_out,
+                               double* f_x0, int* iters, int* nfev, int* status, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
+  if (m < 1 || m > 5) return fail(2, "the device-resident optimiser keeps at most 5 correction pairs");
+  Prof pf(PROF_INDIV_MSTEP, S(stream));
+  return launch_indiv_mstep(M, nmax, off, t, y, idx, mean, cpack, mode, theta0, m, factr, pgtol,
+                            maxit, theta_out, f_out, f_x0, iters, nfev, status, S(stream));
 }
 
 int64_t magma_cpack_stride(int nmax) {

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "mfma_sweep.h"
+#include "lbfgsb_core.h"
 
 namespace magma {
 
@@ -272,40 +273,21 @@ __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
 //  4. T = C K^-1: A fragments straight from the packed C in global memory, B from Ks.
 //  5. Z = K^-1 T: A fragments from Ks, B fragments = T's registers; only tiles on or below the
 //     diagonal, each contracted with K_nl and dK/dtheta2 as soon as it is complete.
+// One evaluation at hyper-parameters (th1, th2, sigma) by this wavefront. tbuf / zbuf hold the
+// individual's timestamps and residuals y - mean (zero beyond n), abuf and Ks are scratch; every
+// lane returns the same f_res, g_res (only with want_grad), info_res.
 template <int NMAX>
-__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
-    int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
-    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
-    const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
-    const double* __restrict__ cpack, int mode, int want_grad,
-    double* __restrict__ f_out, double* __restrict__ g_out, int* __restrict__ info_out) {
+__device__ __forceinline__ void indiv_eval_body(
+    int lane, int n, int i, double th1, double th2, double sigma, const double* tbuf,
+    const double* zbuf, double* abuf, double* Ks, const double* __restrict__ cpack, int mode,
+    int want_grad, double& f_res, double (&g_res)[3], int& info_res) {
   constexpr int NT = (NMAX + 15) / 16;  // 16 x 16 tiles per dimension
   constexpr int NK = NMAX / 4;          // blocks of 4 rows / k-blocks
   constexpr int LD = NMAX;              // row length of Ks
   static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
-  __shared__ double tbuf[64];
-  __shared__ double zbuf[64];
-  __shared__ double abuf[64];
-  // Ks: NMAX * LD + 16 doubles (fragment reads of the last rows run up to 12 doubles past the
-  // end; what they fetch only reaches masked results). During the sweep its first 256 doubles
-  // are the transposition buffer Pn[64][4].
-  extern __shared__ __attribute__((aligned(16))) double Ks[];
-
-  const int lane = threadIdx.x;
   const int l = lane & 15, g = lane >> 4;
-  const int io = blockIdx.x;  // slot of theta / f / g / info (compact when sel is given)
-  const int i = sel ? sel[io] : io;
-  const int64_t o = off[i];
-  const int n = (int)(off[i + 1] - o);
-  const double* th = theta + (int64_t)io * tstride;
-  const double sigma = th[2];
-  const SEParams p = se_params(th[0], th[1], sigma);
-  const bool rv = lane < n;
-  const double tr = rv ? t[o + lane] : 0.0;
-  const double zr = rv ? (y[o + lane] - mean[idx[o + lane]]) : 0.0;
-  tbuf[lane] = tr;
-  zbuf[lane] = zr;
-  __syncthreads();
+  const SEParams p = se_params(th1, th2, sigma);
+  const double zr = zbuf[lane];
   STAMP_INIT();
   const bool have_c = (cpack != nullptr);
   // packed C_i: Cq[kk * 64 * NT + it] = C[16 it + l][4 kk + g] (see indiv_gather_cov_kernel)
@@ -448,10 +430,8 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
       cor = wave_sum(cor);
     }
     STAMP(3);
-    if (lane == 0) {
-      f_out[io] = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
-      info_out[io] = info;
-    }
+    f_res = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
+    info_res = info;
     STAMP_FLUSH();
     return;
   }
@@ -528,21 +508,118 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
     }
   }
   if (with_c) cor = wave_sum(cor);
-  if (lane == 0) {
-    f_out[io] = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
-    info_out[io] = info;
-  }
+  f_res = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
+  info_res = info;
   STAMP(7);
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   s3 = wave_sum(s3);
-  if (lane == 0) {
-    g_out[3 * (int64_t)io + 0] = (info == 0) ? -0.5 * s1 : nanv;
-    g_out[3 * (int64_t)io + 1] = (info == 0) ? -0.5 * s2 : nanv;
-    g_out[3 * (int64_t)io + 2] = (info == 0) ? -sigma * s3 : nanv;
-  }
+  g_res[0] = (info == 0) ? -0.5 * s1 : nanv;
+  g_res[1] = (info == 0) ? -0.5 * s2 : nanv;
+  g_res[2] = (info == 0) ? -sigma * s3 : nanv;
   STAMP(8);
   STAMP_FLUSH();
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
+    int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
+    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
+    const double* __restrict__ cpack, int mode, int want_grad,
+    double* __restrict__ f_out, double* __restrict__ g_out, int* __restrict__ info_out) {
+  __shared__ double tbuf[64];
+  __shared__ double zbuf[64];
+  __shared__ double abuf[64];
+  // Ks: NMAX * NMAX + 16 doubles (fragment reads of the last rows run up to 12 doubles past the
+  // end; what they fetch only reaches masked results). During the sweep its first 256 doubles
+  // are the transposition buffer Pn[64][4].
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
+  const int lane = threadIdx.x;
+  const int io = blockIdx.x;  // slot of theta / f / g / info (compact when sel is given)
+  const int i = sel ? sel[io] : io;
+  const int64_t o = off[i];
+  const int n = (int)(off[i + 1] - o);
+  const double* th = theta + (int64_t)io * tstride;
+  const bool rv = lane < n;
+  tbuf[lane] = rv ? t[o + lane] : 0.0;
+  zbuf[lane] = rv ? (y[o + lane] - mean[idx[o + lane]]) : 0.0;
+  __syncthreads();
+  double f, g[3] = {0.0, 0.0, 0.0};
+  int info;
+  indiv_eval_body<NMAX>(lane, n, i, th[0], th[1], th[2], tbuf, zbuf, abuf, Ks, cpack, mode,
+                        want_grad, f, g, info);
+  if (lane == 0) {
+    f_out[io] = f;
+    info_out[io] = info;
+    if (want_grad) {
+      g_out[3 * (int64_t)io + 0] = g[0];
+      g_out[3 * (int64_t)io + 1] = g[1];
+      g_out[3 * (int64_t)io + 2] = g[2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ device-resident M-step
+// m_step's individual part (CF:419-432: one optim() per individual) without leaving the GPU:
+// the wavefront that evaluates an individual also runs its L-BFGS-B (lbfgsb_core.h, the very
+// code the host driver steps through, so both give the same iterates), evaluation after
+// evaluation, until that problem stops. No host round trip per evaluation and no lock step: a
+// wavefront whose problem has converged retires and the next individual takes its place, so
+// the time is total work / machine width (or the longest single chain), not rounds x latency.
+// The optimiser state (~60 doubles) lives in LDS; every lane steps it redundantly with the
+// same wave-uniform f, g.
+template <int NMAX>
+__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
+    int M, const int64_t* __restrict__ off, const double* __restrict__ t,
+    const double* __restrict__ y, const int* __restrict__ idx, const double* __restrict__ mean,
+    const double* __restrict__ cpack, int mode, const double* __restrict__ theta0, int lm,
+    double factr, double pgtol, int maxit, double* __restrict__ theta_out,
+    double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
+    int* __restrict__ nfev_out, int* __restrict__ status_out) {
+  __shared__ double tbuf[64];
+  __shared__ double zbuf[64];
+  __shared__ double abuf[64];
+  __shared__ lbcore::State<3, 5> st;
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
+  const int i = blockIdx.x;
+  const int64_t o = off[i];
+  const int n = (int)(off[i + 1] - o);
+  {
+    const int lane0 = threadIdx.x;
+    const bool rv = lane0 < n;
+    tbuf[lane0] = rv ? t[o + lane0] : 0.0;
+    zbuf[lane0] = rv ? (y[o + lane0] - mean[idx[o + lane0]]) : 0.0;
+    lbcore::init(st, 3, lm, theta0 + 3 * (int64_t)i);
+  }
+  __syncthreads();
+  double fx0 = 0.0;
+#pragma unroll 1
+  for (int ev = 0;; ++ev) {
+    // lane is laundered per evaluation: otherwise every lane-derived address and mask of the
+    // body is hoisted out of the loop and held in registers across it
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const double th1 = st.xtrial[0], th2 = st.xtrial[1], sigma = st.xtrial[2];
+    double f, g[3] = {0.0, 0.0, 0.0};
+    int info;
+    indiv_eval_body<NMAX>(lane, n, i, th1, th2, sigma, tbuf, zbuf, abuf, Ks, cpack, mode, 1, f,
+                          g, info);
+    if (ev == 0) fx0 = f;
+    __syncthreads();  // the body's LDS traffic is over before the state is stepped
+    lbcore::tell(st, f, g, factr, pgtol, maxit);
+    __syncthreads();
+    if (st.status != 0) break;
+  }
+  if (threadIdx.x == 0) {
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    for (int q = 0; q < 3; ++q) theta_out[3 * (int64_t)i + q] = (st.status == 5) ? nanv : st.x[q];
+    f_out[i] = st.f;
+    fx0_out[i] = fx0;
+    iters_out[i] = st.iter;
+    nfev_out[i] = st.nfev;
+    status_out[i] = st.status;
+  }
 }
 
 // ------------------------------------------------------------------ prediction (MG:172-180)
@@ -686,6 +763,40 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
 #define CALL(NM)                                                                          \
   rc = launch_indiv_eval_t<NM>(nsel, sel, off, t, y, idx, theta, tstride, mean, cpack,   \
                                mode, want_grad, f, g, info, st)
+  MAGMA_DISPATCH_NMAX(nmax, CALL);
+#undef CALL
+  return rc;
+}
+
+template <int NM>
+static int launch_indiv_mstep_t(int M, const int64_t* off, const double* t, const double* y,
+                                const int* idx, const double* mean, const double* cpack, int mode,
+                                const double* theta0, int lm, double factr, double pgtol,
+                                int maxit, double* theta_out, double* f_out, double* fx0_out,
+                                int* iters, int* nfev, int* status, hipStream_t st) {
+  const size_t dyn = ((size_t)NM * NM + 16) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(M), dim3(64), dyn, st, M, off, t, y, idx, mean,
+                     cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out, fx0_out, iters,
+                     nfev, status);
+  return check_hip(hipGetLastError(), "indiv_mstep");
+}
+
+int launch_indiv_mstep(int M, int nmax, const int64_t* off, const double* t, const double* y,
+                       const int* idx, const double* mean, const double* cpack, int mode,
+                       const double* theta0, int lm, double factr, double pgtol, int maxit,
+                       double* theta_out, double* f_out, double* fx0_out, int* iters, int* nfev,
+                       int* status, hipStream_t st) {
+  if (M <= 0) return 0;
+  int rc = 0;
+#define CALL(NM)                                                                               \
+  rc = launch_indiv_mstep_t<NM>(M, off, t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, \
+                                maxit, theta_out, f_out, fx0_out, iters, nfev, status, st)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return rc;

@@ -316,6 +316,42 @@ class HipBackend:
         return {"x": x, "f": f, "f_x0": fx0, "iters": iters, "nfev": nfev, "status": status,
                 "rounds": int(rounds.value)}
 
+    def indiv_mstep_resident(self, theta_start, mode=0, use_cov=True, m=5, factr=1e7, pgtol=0.0,
+                             maxit=100):
+        """The same problems solved by magma_indiv_mstep_resident: one launch, the optimiser
+        runs inside the evaluating wavefronts."""
+        M, torch = self.M, self.torch
+        if M == 0:
+            return self.indiv_mstep(theta_start, mode, use_cov, m, factr, pgtol, maxit)
+        x0 = np.ascontiguousarray(theta_start, dtype=np.float64)
+        assert x0.shape == (M, 3), x0.shape
+        if use_cov and not self._cpack_ok:
+            _lib.call("magma_indiv_gather_cov", M, self.nmax, _ptr(self.off), _ptr(self.idx),
+                      _ptr(self.cov), self.N, _ptr(self.cpack), self.stream())
+            self._cpack_ok = True
+        if getattr(self, "_res", None) is None:
+            f64, i32, dev = torch.float64, torch.int32, self.dev
+            self._res = {"x": torch.empty(3 * M, dtype=f64, device=dev),
+                         "f": torch.empty(M, dtype=f64, device=dev),
+                         "fx0": torch.empty(M, dtype=f64, device=dev),
+                         "it": torch.empty(M, dtype=i32, device=dev),
+                         "nf": torch.empty(M, dtype=i32, device=dev),
+                         "st": torch.empty(M, dtype=i32, device=dev)}
+        r = self._res
+        self.h_theta[:3 * M].numpy()[:] = x0.reshape(-1)
+        self.theta[:3 * M].copy_(self.h_theta[:3 * M], non_blocking=True)
+        _lib.call("magma_indiv_mstep_resident", int(mode), M, self.nmax, _ptr(self.off),
+                  _ptr(self.t), _ptr(self.y), _ptr(self.idx), _ptr(self.mean),
+                  _ptr(self.cpack if use_cov else None), _ptr(self.theta), int(m), float(factr),
+                  float(pgtol), int(maxit), _ptr(r["x"]), _ptr(r["f"]), _ptr(r["fx0"]),
+                  _ptr(r["it"]), _ptr(r["nf"]), _ptr(r["st"]), self.stream())
+        out = {"x": r["x"].cpu().numpy().reshape(M, 3), "f": r["f"].cpu().numpy(),
+               "f_x0": r["fx0"].cpu().numpy(), "iters": r["it"].cpu().numpy(),
+               "nfev": r["nf"].cpu().numpy(), "status": r["st"].cpu().numpy()}
+        out["rounds"] = int(out["nfev"].max())
+        self.n_evals += int(out["nfev"].sum())
+        return out
+
     def theta0_eval(self, theta0, pen_diag, want_grad=True):
         out = (C.c_double * 3)()
         info = C.c_int(0)
@@ -401,7 +437,12 @@ class Engine:
         factory = backend_factory or (lambda d, lo, hi: HipBackend(d, lo, hi, device))
         self.be = factory(ds, self.lo, self.hi)
         self.stats = {"theta0_evals": 0, "indiv_rounds": 0, "common_evals": 0, "flagged": 0}
-        self.native_mstep = True  # False: drive the theta_i rounds from Python (minimize_batch)
+        # theta_i problems of the M-step: "resident" = optimiser inside the evaluating wavefronts
+        # (one launch); True = lock-step rounds driven by the library (magma_indiv_mstep);
+        # False = lock-step rounds driven from Python (minimize_batch)
+        import os
+        self.native_mstep = {"resident": "resident", "native": True, "python": False}[
+            os.environ.get("MAGMA_MSTEP", "resident")]
 
     # ------------------------------------------------------------ E-step (CF:371-395)
     def e_step(self, theta0, theta_i, pen_diag, m0):
@@ -474,7 +515,10 @@ class Engine:
                 self.stats["indiv_rounds"] += 1
                 return self.be.indiv_eval(x, True, active=act)
             if self.hi > self.lo:
-                if hasattr(self.be, "indiv_mstep") and self.native_mstep:
+                if hasattr(self.be, "indiv_mstep_resident") and self.native_mstep == "resident":
+                    ri = self.be.indiv_mstep_resident(theta_i[self.lo:self.hi], **kw)
+                    self.stats["indiv_rounds"] += ri["rounds"]
+                elif hasattr(self.be, "indiv_mstep") and self.native_mstep:
                     ri = self.be.indiv_mstep(theta_i[self.lo:self.hi], **kw)
                     self.stats["indiv_rounds"] += ri["rounds"]
                 else:

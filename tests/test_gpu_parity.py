@@ -319,3 +319,24 @@ def test_native_mstep_loop_equals_python_driven_loop(gpu):
     new = orc.m_step(db, hp, par["mean"], par["cov"], orc.kernel, orc.kernel, 0.3, False)
     exp = np.array([new["theta_i"][i] for i in ids])
     assert np.abs(res[0][1] - exp).max() < 1e-6 * max(1.0, np.abs(exp).max())
+
+
+def test_resident_mstep_equals_lock_step_mstep(gpu):
+    """magma_indiv_mstep_resident (L-BFGS-B stepped inside the evaluating wavefronts) against the
+    host-driven lock-step loop: same optimiser source, same evaluation code -> same iterates."""
+    from magma_amd.engine import Dataset, Engine
+    rng = np.random.default_rng(29)
+    db = _ragged_db(rng, [5, 30, 17, 50, 42, 30, 8, 64, 1, 2])
+    ids = orc.unique_in_order(db["ID"])
+    hp = _random_hp(rng, ids)
+    th0 = hp["theta_0"]
+    thi = np.array([hp["theta_i"][i] for i in ids])
+    eng = Engine(Dataset(db))
+    eng.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.3)
+    a = eng.be.indiv_mstep_resident(thi)
+    b = eng.be.indiv_mstep(thi)
+    assert np.array_equal(a["status"], b["status"]), (a["status"], b["status"])
+    assert np.array_equal(a["nfev"], b["nfev"]) and np.array_equal(a["iters"], b["iters"])
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-12 * max(1.0, np.abs(b["x"]).max())
+    assert np.abs(a["f_x0"] - b["f_x0"]).max() <= 1e-12 * np.abs(b["f_x0"]).max()
+    assert np.abs(a["f"] - b["f"]).max() <= 1e-12 * np.abs(b["f"]).max()
