@@ -52,12 +52,17 @@ def pmc_traffic(kernel_class, evals_per_launch):
     workgroup (= per evaluated individual) figure is scaled to this run's launch size."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                         "r01_pmc_fetch_write.json")
-    if kernel_class != "indiv_eval(f+grad)" or not os.path.exists(path):
+    keys = {"indiv_eval(f+grad)": "magma::indiv_eval_kernel<52>",
+            "indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>"}
+    if kernel_class not in keys or not os.path.exists(path):
         return None
     with open(path) as fh:
         pmc = json.load(fh)
-    key = "magma::indiv_eval_kernel<52>"
+    key = keys[kernel_class]
     try:
+        if kernel_class == "indiv_mstep(resident)":  # always launched over all M individuals
+            kb = 2.0 * pmc["FETCH_SIZE"][key]["avg_kb"] + pmc["WRITE_SIZE"][key]["avg_kb"]
+            return kb * 1024.0
         kb = 2.0 * pmc["FETCH_SIZE"][key]["kb_per_workgroup_at_max"] \
             + pmc["WRITE_SIZE"][key]["kb_per_workgroup_at_max"]
     except KeyError:
@@ -209,7 +214,8 @@ def main():
         value = args.steps * (M_total / 10000.0 if args.config == "c3" else 1.0) / elapsed
         S3 = Mloc * n ** 3
         S2 = Mloc * n ** 2
-        ng = max(1, prof.get("indiv_eval(f+grad)", {}).get("launches", 1))
+        ng = max(1, prof.get("indiv_eval(f+grad)", {}).get("launches", 0)
+                 or prof.get("indiv_mstep(resident)", {}).get("launches", 1))
         # algorithmic work per launch; FP64 FMA peak = FP64 MFMA peak on
         # MI355X, so the per-individual FP64 kernels are priced against the same 78.6 TFLOP/s
         alg = {
@@ -218,6 +224,9 @@ def main():
             "spd_inverse": ("mfma", 1.0 * N ** 3, False),  # composite: ~75 launches per call
             # 5 n^3 flops x the individuals actually evaluated per launch (active list)
             "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * n_evals / ng, True),
+            # device-resident M-step: the same 5 n^3 per evaluation, all evaluations of a launch
+            "indiv_mstep(resident)": ("mfma", 5.0 * n ** 3 * n_evals / max(1, prof.get(
+                "indiv_mstep(resident)", {}).get("launches", 1)), True),
             "indiv_eval(f)": ("mfma", 1.0 * S3, True),
             "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n, True),
         }

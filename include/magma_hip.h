@@ -54,6 +54,11 @@ int magma_stream_sync(void* stream);
  * only, 5 E-step scatter, 6 K_0 build, 7 batched K_i build, 8 batched K_i inverse. */
 int magma_prof_enable(int on);
 int magma_prof_reset(void);
+/* Tunables. "resident_max_workgroups": cap on the grid of magma_indiv_mstep_resident (0 = one
+ * workgroup per individual; otherwise workgroups take individuals in a grid-stride loop). Its
+ * wavefronts fill a SIMD's register file: a cap of 2 per CU leaves half of every CU to the
+ * kernels of other streams (the theta_0 chain). */
+int magma_set_option(const char* name, long value);
 int magma_prof_get(int id, int* h_count, double* h_total_ms);
 
 /* ---- (1) batched SE-kernel covariance ---- */

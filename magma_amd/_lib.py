@@ -40,6 +40,7 @@ SIGNATURES = {
     "magma_spd_inverse": (_i, [_i, _p, _p, _p, _p, _p]),
     "magma_indiv_eval": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p,
                               _p, _p, _p]),
+    "magma_set_option": (_i, [C.c_char_p, C.c_long]),
     "magma_cpack_stride": (_i64, [_i]),
     "magma_indiv_gather_cov": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "magma_theta0_eval": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _i, _p, C.POINTER(_d),

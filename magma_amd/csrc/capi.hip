@@ -323,6 +323,15 @@ int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, co
                             maxit, theta_out, f_out, f_x0, iters, nfev, status, S(stream));
 }
 
+int magma_set_option(const char* name, long value) {
+  if (!name) return fail(2, "option name is NULL");
+  if (std::string(name) == "resident_max_workgroups") {
+    set_resident_max_workgroups((int)value);
+    return 0;
+  }
+  return fail(2, std::string("unknown option: ") + name);
+}
+
 int64_t magma_cpack_stride(int nmax) {
   if (nmax < 1 || nmax > MAGMA_NSMALL_MAX) return 0;
   return (int64_t)cpack_ldp(nmax) * small_template_nmax(nmax);

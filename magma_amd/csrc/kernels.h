@@ -23,6 +23,7 @@ int launch_indiv_mstep(int M, int nmax, const int64_t* off, const double* t, con
                        const double* theta0, int lm, double factr, double pgtol, int maxit,
                        double* theta_out, double* f_out, double* fx0_out, int* iters, int* nfev,
                        int* status, hipStream_t st);
+void set_resident_max_workgroups(int v);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,

@@ -135,7 +135,7 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
       pe += e;
     }
     // evaluate now: otherwise all pivots stay in registers until the end of the sweep
-    asm volatile("" : "+v"(pm), "+v"(pe));
+    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
     // this lane's column g of D, picked with 0/1 weights (exact). A select chain here is turned
     // into divergent branches around the whole D computation by hipcc.
     double dc[4];
@@ -268,7 +268,7 @@ __device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double
       pm = frexp(pm, &e);
       pe += e;
     }
-    asm volatile("" : "+v"(pm), "+v"(pe));
+    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
     // row g of M for this lane (0/1 weights: exact, and no divergent select chains)
     double mr[4];
 #pragma unroll

@@ -22,6 +22,8 @@
 #include "mfma_sweep.h"
 #include "lbfgsb_core.h"
 
+#include <atomic>
+
 namespace magma {
 
 #ifndef MAGMA_INDIV_WAVES
@@ -569,6 +571,16 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
 // the time is total work / machine width (or the longest single chain), not rounds x latency.
 // The optimiser state (~60 doubles) lives in LDS; every lane steps it redundantly with the
 // same wave-uniform f, g.
+// Out of line on purpose: inlined, the optimiser's scalar code shares the register allocation of
+// the evaluation body and pushes it into scratch spills (1 GB of spill traffic per launch at C3).
+__device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>* st, double f,
+                                                             double g0, double g1, double g2,
+                                                             double factr, double pgtol,
+                                                             int maxit) {
+  const double g[3] = {g0, g1, g2};
+  lbcore::tell(*st, f, g, factr, pgtol, maxit);
+}
+
 template <int NMAX>
 __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
     int M, const int64_t* __restrict__ off, const double* __restrict__ t,
@@ -582,20 +594,28 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
   __shared__ double abuf[64];
   __shared__ lbcore::State<3, 5> st;
   extern __shared__ __attribute__((aligned(16))) double Ks[];
-  const int i = blockIdx.x;
-  const int64_t o = off[i];
-  const int n = (int)(off[i + 1] - o);
-  {
-    const int lane0 = threadIdx.x;
-    const bool rv = lane0 < n;
-    tbuf[lane0] = rv ? t[o + lane0] : 0.0;
-    zbuf[lane0] = rv ? (y[o + lane0] - mean[idx[o + lane0]]) : 0.0;
-    lbcore::init(st, 3, lm, theta0 + 3 * (int64_t)i);
-  }
-  __syncthreads();
+  // Grid-stride over the individuals: the launch may be capped to fewer workgroups than
+  // individuals (magma_set_option "resident_max_workgroups") so that these register-file-filling
+  // wavefronts leave SIMDs free for the kernels of other streams.
+  int i = blockIdx.x;
+  int n = 0;
+  bool fresh = true;
   double fx0 = 0.0;
 #pragma unroll 1
-  for (int ev = 0;; ++ev) {
+  for (;;) {
+    if (fresh) {  // wave-uniform
+      if (i >= M) break;
+      __syncthreads();
+      const int64_t o = off[i];
+      n = (int)(off[i + 1] - o);
+      const int lane0 = threadIdx.x;
+      const bool rv = lane0 < n;
+      tbuf[lane0] = rv ? t[o + lane0] : 0.0;
+      zbuf[lane0] = rv ? (y[o + lane0] - mean[idx[o + lane0]]) : 0.0;
+      lbcore::init(st, 3, lm, theta0 + 3 * (int64_t)i);
+      __syncthreads();
+      fresh = false;
+    }
     // lane is laundered per evaluation: otherwise every lane-derived address and mask of the
     // body is hoisted out of the loop and held in registers across it
     int lane = threadIdx.x;
@@ -605,20 +625,24 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
     int info;
     indiv_eval_body<NMAX>(lane, n, i, th1, th2, sigma, tbuf, zbuf, abuf, Ks, cpack, mode, 1, f,
                           g, info);
-    if (ev == 0) fx0 = f;
+    fx0 = (st.nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
     __syncthreads();  // the body's LDS traffic is over before the state is stepped
-    lbcore::tell(st, f, g, factr, pgtol, maxit);
+    lbfgsb_tell_device(&st, f, g[0], g[1], g[2], factr, pgtol, maxit);
     __syncthreads();
-    if (st.status != 0) break;
-  }
-  if (threadIdx.x == 0) {
-    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-    for (int q = 0; q < 3; ++q) theta_out[3 * (int64_t)i + q] = (st.status == 5) ? nanv : st.x[q];
-    f_out[i] = st.f;
-    fx0_out[i] = fx0;
-    iters_out[i] = st.iter;
-    nfev_out[i] = st.nfev;
-    status_out[i] = st.status;
+    if (st.status != 0) {
+      if (threadIdx.x == 0) {
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+        for (int q = 0; q < 3; ++q)
+          theta_out[3 * (int64_t)i + q] = (st.status == 5) ? nanv : st.x[q];
+        f_out[i] = st.f;
+        fx0_out[i] = fx0;
+        iters_out[i] = st.iter;
+        nfev_out[i] = st.nfev;
+        status_out[i] = st.status;
+      }
+      i += gridDim.x;
+      fresh = true;
+    }
   }
 }
 
@@ -768,6 +792,10 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
   return rc;
 }
 
+// 0 = one workgroup per individual; > 0 caps the grid of the device-resident M-step.
+static std::atomic<int> g_resident_max_wgs{0};
+void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
+
 template <int NM>
 static int launch_indiv_mstep_t(int M, const int64_t* off, const double* t, const double* y,
                                 const int* idx, const double* mean, const double* cpack, int mode,
@@ -781,7 +809,9 @@ static int launch_indiv_mstep_t(int M, const int64_t* off, const double* t, cons
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     attr_set = true;
   }
-  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(M), dim3(64), dyn, st, M, off, t, y, idx, mean,
+  const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
+  const int grid = (cap > 0 && M > cap) ? cap : M;
+  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64), dyn, st, M, off, t, y, idx, mean,
                      cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out, fx0_out, iters,
                      nfev, status);
   return check_hip(hipGetLastError(), "indiv_mstep");

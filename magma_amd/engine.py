@@ -443,6 +443,8 @@ class Engine:
         import os
         self.native_mstep = {"resident": "resident", "native": True, "python": False}[
             os.environ.get("MAGMA_MSTEP", "resident")]
+        # workgroups of the resident kernel while the theta_0 chain runs next to it (0 = no cap)
+        self.resident_wg_cap = int(os.environ.get("MAGMA_RESIDENT_WGS", 0))
 
     # ------------------------------------------------------------ E-step (CF:371-395)
     def e_step(self, theta0, theta_i, pen_diag, m0):
@@ -516,6 +518,8 @@ class Engine:
                 return self.be.indiv_eval(x, True, active=act)
             if self.hi > self.lo:
                 if hasattr(self.be, "indiv_mstep_resident") and self.native_mstep == "resident":
+                    cap = self.resident_wg_cap if fut0 is not None else 0
+                    _lib.call("magma_set_option", b"resident_max_workgroups", cap)
                     ri = self.be.indiv_mstep_resident(theta_i[self.lo:self.hi], **kw)
                     self.stats["indiv_rounds"] += ri["rounds"]
                 elif hasattr(self.be, "indiv_mstep") and self.native_mstep:
