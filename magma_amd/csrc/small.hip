@@ -138,6 +138,65 @@ __global__ __launch_bounds__(256) void se_cov_batched_kernel(
   }
 }
 
+// ------------------------------------------------------------------ K(theta)^-1 into LDS
+// Build the SE covariance of one individual in accumulator layout (identity padded to NMAX),
+// invert it with the blocked MFMA sweep (mfma_sweep.h; scaled to a unit diagonal first) and
+// leave K^-1 in LDS as Ks[r * NMAX + c] (symmetric). Ks: NMAX * NMAX + 16 doubles, its head
+// doubles as the sweep's transposition buffer. Ends with a barrier.
+template <int NMAX>
+__device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParams& p,
+                                                  const double* tbuf, double* Ks, double& logdet,
+                                                  int& info) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4, LD = NMAX;
+  static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
+  const int l = lane & 15, g = lane >> 4;
+  const double sc = 1.0 / (p.eth1 + p.sig2);
+  v4d A[NT][NT];
+  double tcol[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
+        continue;
+      }
+      const int r = 16 * it + 4 * v + g;
+      const double trow = tbuf[r];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        const double d = trow - tcol[jt];
+        double kv = exp(p.th1 - p.h * d * d) * sc;
+        kv = (r == c) ? 1.0 : kv;
+        A[it][jt][v] = (r < n && c < n) ? kv : ((r == c) ? 1.0 : 0.0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
+      }
+    }
+  }
+  double pm = 1.0;
+  int pe = 0;
+  info = 0;
+  mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
+  logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) continue;
+      const int r = 16 * it + 4 * v + g;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
+      }
+    }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------ K1+K3: inverse to HBM
 template <int NMAX>
 __global__ __launch_bounds__(64) void se_inv_batched_kernel(
@@ -145,25 +204,22 @@ __global__ __launch_bounds__(64) void se_inv_batched_kernel(
     const double* __restrict__ t, const double* __restrict__ theta, int tstride,
     double* __restrict__ out, double* __restrict__ logdet_out, int* __restrict__ info_out) {
   __shared__ double tbuf[64];
-  __shared__ __attribute__((aligned(16))) double colbuf[64];
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
   const int i = blockIdx.x, lane = threadIdx.x;
   const int64_t o = off[i];
   const int n = (int)(off[i + 1] - o);
   const double* th = theta + (int64_t)i * tstride;
   const SEParams p = se_params(th[0], th[1], th[2]);
-  const double tr = (lane < n) ? t[o + lane] : 0.0;
-  tbuf[lane] = tr;
+  tbuf[lane] = (lane < n) ? t[o + lane] : 0.0;
   __syncthreads();
-  double a[NMAX];
-  build_row<NMAX>(a, lane, n, tr, tbuf, p);
   double logdet;
   int info;
-  sweep_inverse<NMAX>(a, lane, colbuf, logdet, info);
+  se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
   double* Kinv = out + off2[i];
   if (lane < n) {
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
-      if (c < n) Kinv[(int64_t)c * n + lane] = a[c];
+      if (c < n) Kinv[(int64_t)c * n + lane] = Ks[c * NMAX + lane];
   }
   if (lane == 0) {
     logdet_out[i] = logdet;
@@ -184,34 +240,31 @@ __global__ __launch_bounds__(64) void estep_scatter_kernel(
   __shared__ double tbuf[64];
   __shared__ double ybuf[64];
   __shared__ int ibuf[64];
-  __shared__ __attribute__((aligned(16))) double colbuf[64];
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
   const int i = blockIdx.x, lane = threadIdx.x;
   const int64_t o = off[i];
   const int n = (int)(off[i + 1] - o);
   const double* th = theta + (int64_t)i * tstride;
   const SEParams p = se_params(th[0], th[1], th[2]);
   const bool rv = lane < n;
-  const double tr = rv ? t[o + lane] : 0.0;
   const int ir = rv ? idx[o + lane] : 0;
-  tbuf[lane] = tr;
+  tbuf[lane] = rv ? t[o + lane] : 0.0;
   ybuf[lane] = rv ? y[o + lane] : 0.0;
   ibuf[lane] = ir;
   __syncthreads();
-  double a[NMAX];
-  build_row<NMAX>(a, lane, n, tr, tbuf, p);
   double logdet;
   int info;
-  sweep_inverse<NMAX>(a, lane, colbuf, logdet, info);
+  se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
   if (lane == 0) info_out[i] = info;
   if (info != 0) return;  // flagged: contributes nothing; the host reports it
-  double wi = 0.0;
+  if (rv) {  // lane r owns row r = column r of K^-1: Ks[c * NMAX + r] is conflict free
+    double wi = 0.0;
 #pragma unroll
-  for (int c = 0; c < NMAX; ++c) wi = fma(a[c], ybuf[c], wi);
-  if (rv) {
+    for (int c = 0; c < NMAX; ++c) wi = fma(Ks[c * NMAX + lane], ybuf[c], wi);
     unsafeAtomicAdd(&w[ir], wi);
 #pragma unroll
     for (int c = 0; c < NMAX; ++c) {
-      if (c <= lane) unsafeAtomicAdd(&P[(int64_t)ibuf[c] * ldp + ir], a[c]);
+      if (c <= lane) unsafeAtomicAdd(&P[(int64_t)ibuf[c] * ldp + ir], Ks[c * NMAX + lane]);
     }
   }
 }
@@ -741,9 +794,9 @@ int launch_se_inv_batched(int M, int nmax, const int64_t* off, const int64_t* of
                           const double* t, const double* theta, int tstride, double* out,
                           double* logdet, int* info, hipStream_t st) {
   if (M <= 0) return 0;
-#define CALL(NM)                                                                            \
-  hipLaunchKernelGGL(se_inv_batched_kernel<NM>, dim3(M), dim3(64), 0, st, M, off, off2, t, \
-                     theta, tstride, out, logdet, info)
+#define CALL(NM)                                                                              \
+  hipLaunchKernelGGL(se_inv_batched_kernel<NM>, dim3(M), dim3(64), (NM * NM + 16) * sizeof(double), \
+                     st, M, off, off2, t, theta, tstride, out, logdet, info)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "se_inv_batched");
@@ -753,9 +806,9 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
                          const int* idx, const double* theta, int tstride, double* P,
                          int64_t ldp, double* w, int* info, hipStream_t st) {
   if (M <= 0) return 0;
-#define CALL(NM)                                                                          \
-  hipLaunchKernelGGL(estep_scatter_kernel<NM>, dim3(M), dim3(64), 0, st, M, off, t, y,   \
-                     idx, theta, tstride, P, ldp, w, info)
+#define CALL(NM)                                                                             \
+  hipLaunchKernelGGL(estep_scatter_kernel<NM>, dim3(M), dim3(64), (NM * NM + 16) * sizeof(double), \
+                     st, M, off, t, y, idx, theta, tstride, P, ldp, w, info)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "estep_scatter");
