@@ -220,7 +220,9 @@ def main():
         # MI355X, so the per-individual FP64 kernels are priced against the same 78.6 TFLOP/s
         alg = {
             "gemm_nt(T=Kinv*C)": ("mfma", 2.0 * N ** 3, True),
-            "theta0_contract": ("mfma", 2.0 * N ** 3, True),
+            # Z = T K^-1 is symmetric: only its lower tiles are formed (N^3 executed of the 2 N^3
+            # a full product would take); priced on what runs
+            "theta0_contract": ("mfma", 1.0 * N ** 3, True),
             "spd_inverse": ("mfma", 1.0 * N ** 3, False),  # composite: ~75 launches per call
             # 5 n^3 flops x the individuals actually evaluated per launch (active list)
             "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * n_evals / ng, True),
