@@ -144,12 +144,16 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
  * individual also steps its L-BFGS-B (the code magma_lbfgsb_* runs on the host, compiled for
  * the device), evaluation after evaluation, until that problem stops; no round trips, no lock
  * step. All pointers are DEVICE memory: theta0[3M] in; theta_out[3M], f_out[M], f_x0[M],
- * iters[M], nfev[M], status[M] out (same meaning as above). m <= 5. Asynchronous on stream. */
+ * iters[M], nfev[M], status[M] out (same meaning as above). order (optional): a permutation of
+ * 0..M-1, the order in which individuals are started -- the launch lasts as long as its longest
+ * chain of evaluations, so start the expected longest first (e.g. by the previous EM
+ * iteration's nfev); results do not depend on it. m <= 5. Asynchronous on stream. */
 int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,
                                const double* y, const int* idx, const double* mean,
-                               const double* cpack, const double* theta0, int m, double factr,
-                               double pgtol, int maxit, double* theta_out, double* f_out,
-                               double* f_x0, int* iters, int* nfev, int* status, void* stream);
+                               const double* cpack, const double* theta0, const int* order,
+                               int m, double factr, double pgtol, int maxit, double* theta_out,
+                               double* f_out, double* f_x0, int* iters, int* nfev, int* status,
+                               void* stream);
 /* logL_GP_mod + gr_GP_mod at theta_0 (CF:181-201, 304-332 with length(hp) == 2: sigma :=
  * pen_diag, two gradients): db = hyper-posterior mean on the grid, mean = m0, new_cov = cov.
  * h_out3 = (f, df/dtheta1, df/dtheta2) on the HOST; h_info as above. Synchronises. */

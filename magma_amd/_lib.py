@@ -58,7 +58,7 @@ SIGNATURES = {
     "magma_indiv_mstep": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _d, _d, _i,
                                _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i),
                                C.POINTER(_i64), _p]),
-    "magma_indiv_mstep_resident": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _d, _d, _i,
+    "magma_indiv_mstep_resident": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _d, _i,
                                         _p, _p, _p, _p, _p, _p, _p]),
     "magma_lbfgsb_result": (_i, [_p, _p, _p, _p, _p, _p]),
     "magma_lbfgsb_destroy": (None, [_p]),

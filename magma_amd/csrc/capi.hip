@@ -312,14 +312,15 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
 
 int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,
                                const double* y, const int* idx, const double* mean,
-                               const double* cpack, const double* theta0, int m, double factr,
-                               double pgtol, int maxit, double* theta_out, double* f_out,
-                               double* f_x0, int* iters, int* nfev, int* status, void* stream) {
+                               const double* cpack, const double* theta0, const int* order,
+                               int m, double factr, double pgtol, int maxit, double* theta_out,
+                               double* f_out, double* f_x0, int* iters, int* nfev, int* status,
+                               void* stream) {
   if (int rc = check_small(M, nmax)) return rc;
   if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
   if (m < 1 || m > 5) return fail(2, "the device-resident optimiser keeps at most 5 correction pairs");
   Prof pf(PROF_INDIV_MSTEP, S(stream));
-  return launch_indiv_mstep(M, nmax, off, t, y, idx, mean, cpack, mode, theta0, m, factr, pgtol,
+  return launch_indiv_mstep(M, nmax, order, off, t, y, idx, mean, cpack, mode, theta0, m, factr, pgtol,
                             maxit, theta_out, f_out, f_x0, iters, nfev, status, S(stream));
 }
 

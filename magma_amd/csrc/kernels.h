@@ -18,7 +18,8 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
                       const double* y, const int* idx, const double* theta, int tstride,
                       const double* mean, const double* cpack, int mode, int want_grad,
                       double* f, double* g, int* info, hipStream_t st);
-int launch_indiv_mstep(int M, int nmax, const int64_t* off, const double* t, const double* y,
+int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, const double* t,
+                       const double* y,
                        const int* idx, const double* mean, const double* cpack, int mode,
                        const double* theta0, int lm, double factr, double pgtol, int maxit,
                        double* theta_out, double* f_out, double* fx0_out, int* iters, int* nfev,

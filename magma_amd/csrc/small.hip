@@ -636,9 +636,10 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
 
 template <int NMAX>
 __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
-    int M, const int64_t* __restrict__ off, const double* __restrict__ t,
-    const double* __restrict__ y, const int* __restrict__ idx, const double* __restrict__ mean,
-    const double* __restrict__ cpack, int mode, const double* __restrict__ theta0, int lm,
+    int M, const int* __restrict__ order, const int64_t* __restrict__ off,
+    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ mean, const double* __restrict__ cpack, int mode,
+    const double* __restrict__ theta0, int lm,
     double factr, double pgtol, int maxit, double* __restrict__ theta_out,
     double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
     int* __restrict__ nfev_out, int* __restrict__ status_out) {
@@ -650,14 +651,17 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
   // Grid-stride over the individuals: the launch may be capped to fewer workgroups than
   // individuals (magma_set_option "resident_max_workgroups") so that these register-file-filling
   // wavefronts leave SIMDs free for the kernels of other streams.
-  int i = blockIdx.x;
-  int n = 0;
+  // Slots are taken in `order` when given (longest expected chain first: the launch ends with
+  // its longest chain, so that one should start at time zero).
+  int slot = blockIdx.x;
+  int i = 0, n = 0;
   bool fresh = true;
   double fx0 = 0.0;
 #pragma unroll 1
   for (;;) {
     if (fresh) {  // wave-uniform
-      if (i >= M) break;
+      if (slot >= M) break;
+      i = order ? order[slot] : slot;
       __syncthreads();
       const int64_t o = off[i];
       n = (int)(off[i + 1] - o);
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
         nfev_out[i] = st.nfev;
         status_out[i] = st.status;
       }
-      i += gridDim.x;
+      slot += gridDim.x;
       fresh = true;
     }
   }
@@ -850,7 +854,8 @@ static std::atomic<int> g_resident_max_wgs{0};
 void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
 
 template <int NM>
-static int launch_indiv_mstep_t(int M, const int64_t* off, const double* t, const double* y,
+static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, const double* t,
+                                const double* y,
                                 const int* idx, const double* mean, const double* cpack, int mode,
                                 const double* theta0, int lm, double factr, double pgtol,
                                 int maxit, double* theta_out, double* f_out, double* fx0_out,
@@ -864,13 +869,15 @@ static int launch_indiv_mstep_t(int M, const int64_t* off, const double* t, cons
   }
   const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
   const int grid = (cap > 0 && M > cap) ? cap : M;
-  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64), dyn, st, M, off, t, y, idx, mean,
+  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64), dyn, st, M, order, off, t, y, idx,
+                     mean,
                      cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out, fx0_out, iters,
                      nfev, status);
   return check_hip(hipGetLastError(), "indiv_mstep");
 }
 
-int launch_indiv_mstep(int M, int nmax, const int64_t* off, const double* t, const double* y,
+int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, const double* t,
+                       const double* y,
                        const int* idx, const double* mean, const double* cpack, int mode,
                        const double* theta0, int lm, double factr, double pgtol, int maxit,
                        double* theta_out, double* f_out, double* fx0_out, int* iters, int* nfev,
@@ -878,7 +885,7 @@ int launch_indiv_mstep(int M, int nmax, const int64_t* off, const double* t, con
   if (M <= 0) return 0;
   int rc = 0;
 #define CALL(NM)                                                                               \
-  rc = launch_indiv_mstep_t<NM>(M, off, t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, \
+  rc = launch_indiv_mstep_t<NM>(M, order, off, t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, \
                                 maxit, theta_out, f_out, fx0_out, iters, nfev, status, st)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL

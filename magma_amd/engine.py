@@ -340,15 +340,24 @@ class HipBackend:
         r = self._res
         self.h_theta[:3 * M].numpy()[:] = x0.reshape(-1)
         self.theta[:3 * M].copy_(self.h_theta[:3 * M], non_blocking=True)
+        order = None
+        if getattr(self, "_last_nfev", None) is not None and self._last_nfev.shape[0] == M:
+            # longest chains of the previous call first (they tend to stay the longest)
+            perm = np.argsort(-self._last_nfev, kind="stable").astype(np.int32)
+            self.h_sel[:M].numpy()[:] = perm
+            self.sel[:M].copy_(self.h_sel[:M], non_blocking=True)
+            order = self.sel
         _lib.call("magma_indiv_mstep_resident", int(mode), M, self.nmax, _ptr(self.off),
                   _ptr(self.t), _ptr(self.y), _ptr(self.idx), _ptr(self.mean),
-                  _ptr(self.cpack if use_cov else None), _ptr(self.theta), int(m), float(factr),
+                  _ptr(self.cpack if use_cov else None), _ptr(self.theta), _ptr(order), int(m),
+                  float(factr),
                   float(pgtol), int(maxit), _ptr(r["x"]), _ptr(r["f"]), _ptr(r["fx0"]),
                   _ptr(r["it"]), _ptr(r["nf"]), _ptr(r["st"]), self.stream())
         out = {"x": r["x"].cpu().numpy().reshape(M, 3), "f": r["f"].cpu().numpy(),
                "f_x0": r["fx0"].cpu().numpy(), "iters": r["it"].cpu().numpy(),
                "nfev": r["nf"].cpu().numpy(), "status": r["st"].cpu().numpy()}
         out["rounds"] = int(out["nfev"].max())
+        self._last_nfev = out["nfev"].astype(np.int64)
         self.n_evals += int(out["nfev"].sum())
         return out
 
