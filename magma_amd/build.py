@@ -12,8 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagma_hip.so")
-SOURCES = ["small.hip", "dense.hip", "capi.hip", "lbfgsb.cpp"]
-HEADERS = ["common.h", "kernels.h", "mfma_sweep.h", "lbfgsb_core.h", os.path.join("..", "..", "include", "magma_hip.h")]
+SOURCES = ["small.hip", "dense.hip", "dense_dag.hip", "capi.hip", "lbfgsb.cpp"]
+HEADERS = ["common.h", "kernels.h", "mfma_sweep.h", "dense_tile.h", "lbfgsb_core.h", os.path.join("..", "..", "include", "magma_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-mllvm", "-pragma-unroll-threshold=200000"]

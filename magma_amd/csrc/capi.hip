@@ -330,6 +330,15 @@ int magma_set_option(const char* name, long value) {
     set_resident_max_workgroups((int)value);
     return 0;
   }
+  if (std::string(name) == "dag_workgroups") {
+    if (value < 0 || value > 4096) return fail(2, "dag_workgroups must be in 0..4096");
+    set_dag_workgroups((int)value);
+    return 0;
+  }
+  if (std::string(name) == "dag_stamps") {  // device buffer of 8 int64 per ticket; diagnostic builds
+    set_dag_stamps(reinterpret_cast<void*>(value));
+    return 0;
+  }
   return fail(2, std::string("unknown option: ") + name);
 }
 

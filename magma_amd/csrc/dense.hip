@@ -13,22 +13,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "mfma_sweep.h"
+#include "dense_tile.h"
 
 namespace magma {
-
-constexpr int TLD = 80;  // LDS row length (doubles) of a staged 16 x 64 operand slab
-constexpr int NB = 64;
-
-struct TileAcc {
-  v4d c[2][2];  // [ni][mi]
-};
-
-__device__ __forceinline__ void tile_zero(TileAcc& acc) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc.c[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-}
 
 // acc(m, n) += sum_k Aop(m, k) * Bop(n, k), Aop(m,k) = Ap[m + k*lda], Bop(n,k) = Bp[n + k*ldb],
 // m, n in [0,64), k in [0, 16*ksteps). As, Bs: 16*TLD doubles of LDS each.
@@ -73,23 +60,6 @@ __device__ __forceinline__ void tile_gemm_nt(const double* __restrict__ Ap, int6
       acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc.c[1][1], 0, 0, 0);
     }
   }
-}
-
-// Visit every accumulator element of this thread: fn(m, n, value&).
-template <class F>
-__device__ __forceinline__ void tile_foreach(TileAcc& acc, F fn) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = wm * 32 + mi * 16 + (lane & 15);
-        const int n = wn * 32 + ni * 16 + (lane >> 4) + 4 * r;
-        fn(m, n, (double)acc.c[ni][mi][r]);
-      }
 }
 
 // ------------------------------------------------------------------ K2: SE covariance on the grid
@@ -709,6 +679,7 @@ size_t spd_inverse_workspace_doubles(int Np) { return 3 * (size_t)Np * Np; }
 
 int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* work,
                        hipStream_t st) {
+  if (spd_inverse_dag_supported(Np)) return launch_spd_inverse_dag(Np, A, logdet, info, work, st);
   const int nt = Np / NB;
   const int64_t ld = Np;
   double* X = work;

@@ -1,0 +1,483 @@
+// Dense SPD inverse + log-det as ONE launch: the tile tasks of a left-looking blocked Cholesky,
+// of the triangular inverse and of A^-1 = L^-T L^-1 form a dependency graph that persistent
+// workgroups walk in ticket order, handing tiles to each other through memory inside the launch.
+//
+// Why: at N = 2000 the launch-per-step factorisation (dense.hip) is a chain of 2 x 32 dependent
+// launches + 11 for the triangular inverse, each paying launch, fill and drain; the matrix cores
+// idle (4-5 % of FP64 peak). Here a step of the chain is: diagonal tile factored -> flag ->
+// tile below it finished -> flag -> next diagonal tile, while every other tile has already
+// accumulated all but its last product, the rows of L^-T follow one step behind the
+// factorisation, and A^-1's tiles accumulate as the rows they need appear.
+//
+// Tasks (nt = Np / 64 block rows), in ticket order -- a task depends only on earlier tickets, so a
+// workgroup that spins on a flag always waits for a workgroup that is already running, whatever
+// the grid size and whatever else occupies the chip (no co-residency assumption):
+//   for j = 0 .. nt-1:
+//     F(j,j)        S = A_jj - sum_{k<j} L_jk L_jk^T;  X_jj = chol(S)^-1, U_jj = X_jj^T
+//     F(i,j), i>j   L_ij = (A_ij - sum_{k<j} L_ik L_jk^T) X_jj^T
+//     T(c,j), c<j   U_cj = -(sum_{c<=k<j} U_ck L_jk^T) X_jj^T        (U = L^-T, upper triangular)
+//   I(i,j), i>=j    Ainv_ij = sum_{k>=i} U_ik U_jk^T, mirrored
+// Hand-off (guide: MI355X_MICROARCH, inter-workgroup visibility, first row of the table): tiles
+// another workgroup reads are written with write-through 16-byte stores (sc1), every storing
+// wavefront drains its stores, a workgroup barrier, then ONE lane raises the tile's flag with an
+// sc1 store; consumers poll flags with sc1 loads from one wavefront, pass a workgroup barrier,
+// and load the tile with sc1 loads only. L, U and the flags live in the caller's workspace and
+// are never read before they are written in a launch; the input A is only read, the output is
+// written by the I tasks, which finish after every read of A (plain stores: the next kernel on
+// the stream reads them).
+// Every spin is bounded: a workgroup that waits ~seconds raises the abort word, every workgroup
+// leaves at its next poll or ticket, and info is set to -999.
+#include "common.h"
+#include "kernels.h"
+#include "mfma_sweep.h"
+#include "dense_tile.h"
+
+namespace magma {
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+#define MAGMA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int AUX_SC1 = 16;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+struct DagArgs {
+  const double* A;  // input (lower tiles read) and output (full symmetric inverse)
+  double* Aout;
+  double* L;   // strictly lower tiles: L_ij; diagonal tiles: X_jj = L_jj^-1
+  double* U;   // upper tiles incl. diagonal: U = L^-T
+  int* fL;     // nt x nt flags, [i * nt + k]: tile (i, k) of L published (k == i: X_ii and U_ii)
+  int* fU;     // nt x nt flags, [c * nt + k]: tile (c, k) of U published (k == c: same as fL)
+  int* ctrl;   // [0] ticket counter, [1] abort word
+  double* logdet;
+  int* info;
+  long long* stamps;  // diagnostic (MAGMA_DAG_STAMPS builds): 8 wall-clock stamps per ticket
+  int nt;
+  int ld;  // = Np (elements); every tile offset fits 32 bits of BYTES (checked by the launcher)
+};
+
+__device__ __forceinline__ rsrc_t make_rsrc(const double* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Wait until the flags fA[k..] and fB[k..] are up for at least tile k; returns the first tile
+// index (<= k1) not known to be published, or -1 when the launch is being abandoned. Called by
+// every thread of the workgroup (contains barriers); the first wavefront polls up to 32 flags of
+// each row at once so that a tile whose operands were published long ago polls once.
+__device__ __forceinline__ int poll_ready(const int* fA, const int* fB, int k, int k1, int* ctrl,
+                                          int* s_ready) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int kk = k + (lane & 31);
+    const int* f = (lane < 32) ? fA : fB;
+    int r = 0;
+    for (unsigned spins = 0;; ++spins) {
+      const int v = (kk < k1) ? __hip_atomic_load(f + kk, MAGMA_RLX_AGENT) : 1;
+      const unsigned long long m = __ballot(v != 0);
+      const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+      const int ra = (lo == 0xffffffffu) ? 32 : __builtin_ctz(~lo);
+      const int rb = (hi == 0xffffffffu) ? 32 : __builtin_ctz(~hi);
+      r = ra < rb ? ra : rb;
+      if (r > 0) break;
+      __builtin_amdgcn_s_sleep(8);
+      if ((spins & 255u) == 255u) {
+        int ab = __hip_atomic_load(ctrl + 1, MAGMA_RLX_AGENT);
+        if (spins >= SPIN_LIMIT) {
+          ab = 1;
+          if (lane == 0) __hip_atomic_store(ctrl + 1, 1, MAGMA_RLX_AGENT);
+        }
+        if (ab != 0) {
+          r = -1;
+          break;
+        }
+      }
+    }
+    if (lane == 0) {
+      int rdy = k + r;
+      if (rdy > k1) rdy = k1;
+      *s_ready = (r > 0) ? rdy : -1;
+    }
+  }
+  __syncthreads();
+  const int ready = *s_ready;
+  __syncthreads();
+  return ready;
+}
+
+// acc(m, n) += sum over tiles k0 <= k < k1 of sum_kk Arow(m, 64 k + kk) Brow(n, 64 k + kk),
+// Arow / Brow = block rows (64 x Np, column-major) at ELEMENT offsets offA / offB of the buffers
+// behind ra / rb; tile k of each row is loaded only after its flag (fA[k], fB[k]) is up.
+// A whole 64 x 64 tile of each operand is fetched at once (16 loads of 16 bytes per thread in
+// flight: one memory latency per tile, which is what the chain of diagonal tiles sees) and fed
+// to LDS in four 16-column slabs; the next tile's loads are issued under the last slab's MFMAs.
+// Returns false when the launch is being abandoned.
+__device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
+                                         unsigned offB, const int* fB, int k0, int k1, int ld,
+                                         TileAcc& acc, double* As, double* Bs, int* ctrl,
+                                         int* s_ready) {
+  if (k0 >= k1) return true;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int x4 = (tid & 15) * 4, kr = tid >> 4;
+  const int fo = (lane >> 4) * TLD + (lane & 15);
+  int ready = poll_ready(fA, fB, k0, k1, ctrl, s_ready);
+  if (ready < 0) return false;
+  v4u ta[4][2], tb[4][2];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned col = (unsigned)(64 * k + 16 * s + kr) * (unsigned)ld;
+      const unsigned oa = (offA + x4 + col) * 8u, ob = (offB + x4 + col) * 8u;
+      ta[s][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa, 0, AUX_SC1);
+      ta[s][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa + 16u, 0, AUX_SC1);
+      tb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob, 0, AUX_SC1);
+      tb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob + 16u, 0, AUX_SC1);
+    }
+  };
+  fetch(k0);
+#pragma unroll 1
+  for (int k = k0; k < k1; ++k) {
+    const bool more = k + 1 < k1;
+    const bool pf = more && (k + 1) < ready;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __syncthreads();
+      *reinterpret_cast<v4u*>(&As[kr * TLD + x4]) = ta[s][0];
+      *reinterpret_cast<v4u*>(&As[kr * TLD + x4 + 2]) = ta[s][1];
+      *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4]) = tb[s][0];
+      *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4 + 2]) = tb[s][1];
+      __syncthreads();
+      if (s == 3 && pf) fetch(k + 1);
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) {
+        const double fa0 = As[kk * TLD + fo + wm * 32];
+        const double fa1 = As[kk * TLD + fo + wm * 32 + 16];
+        const double fb0 = Bs[kk * TLD + fo + wn * 32];
+        const double fb1 = Bs[kk * TLD + fo + wn * 32 + 16];
+        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
+        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
+        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
+      }
+    }
+    if (more && !pf) {
+      ready = poll_ready(fA, fB, k + 1, k1, ctrl, s_ready);
+      if (ready < 0) return false;
+      fetch(k + 1);
+    }
+  }
+  return true;
+}
+
+// out(m, n) = sum_k V(m, k) X(n, k): V staged in LDS as Vs[k * TLD + m] (64 rows of TLD), X = the
+// 64 x 64 tile at element offset offX of rx (column-major, ld), published behind flag fX.
+__device__ __forceinline__ bool times_xt(const double* Vs, rsrc_t rx, unsigned offX, const int* fX,
+                                         int ld, TileAcc& out, double* Bs, int* ctrl,
+                                         int* s_ready, long long* stamp2) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int x4 = (tid & 15) * 4, kr = tid >> 4;
+  const int fo = (lane >> 4) * TLD + (lane & 15);
+  if (poll_ready(fX, fX, 0, 1, ctrl, s_ready) < 0) return false;  // (also publishes Vs)
+#ifdef MAGMA_DAG_STAMPS
+  if (stamp2 != nullptr && threadIdx.x == 0) *stamp2 = (long long)wall_clock64();
+#endif
+  v4u tb[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned ob = (offX + x4 + (unsigned)(16 * s + kr) * (unsigned)ld) * 8u;
+    tb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, ob, 0, AUX_SC1);
+    tb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, ob + 16u, 0, AUX_SC1);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    __syncthreads();
+    *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4]) = tb[s][0];
+    *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4 + 2]) = tb[s][1];
+    __syncthreads();
+    const double* Va = Vs + 16 * s * TLD;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+      const double fa0 = Va[kk * TLD + fo + wm * 32];
+      const double fa1 = Va[kk * TLD + fo + wm * 32 + 16];
+      const double fb0 = Bs[kk * TLD + fo + wn * 32];
+      const double fb1 = Bs[kk * TLD + fo + wn * 32 + 16];
+      out.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, out.c[0][0], 0, 0, 0);
+      out.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, out.c[0][1], 0, 0, 0);
+      out.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, out.c[1][0], 0, 0, 0);
+      out.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, out.c[1][1], 0, 0, 0);
+    }
+  }
+  return true;
+}
+
+// acc <- -A(m, n) for the 64 x 64 tile at A (plain loads: the input is only read in this launch).
+__device__ __forceinline__ void tile_load_neg(TileAcc& acc, const double* __restrict__ A, int ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = wm * 32 + mi * 16 + (lane & 15);
+        const int n = wn * 32 + ni * 16 + (lane >> 4) + 4 * r;
+        acc.c[ni][mi][r] = -A[m + (int64_t)n * ld];
+      }
+}
+
+// Publish the 64 x 64 tile staged in LDS as Ts[n * TLD + m] (column n, row m) to element offset
+// off of rd: write-through 16-byte stores, 512 contiguous bytes per half wavefront.
+__device__ __forceinline__ void store_tile_sc1(const double* Ts, rsrc_t rd, unsigned off, int ld) {
+  const int tid = threadIdx.x;
+  const int m2 = (tid & 31) * 2;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int n = c * 8 + (tid >> 5);
+    const v4u v = *reinterpret_cast<const v4u*>(&Ts[n * TLD + m2]);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rd, (off + m2 + (unsigned)n * (unsigned)ld) * 8u, 0,
+                                           AUX_SC1);
+  }
+}
+
+// Every storing wavefront has drained, then one lane raises the flag(s).
+__device__ __forceinline__ void publish(int* f0, int* f1) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(f0, 1, MAGMA_RLX_AGENT);
+    if (f1 != nullptr) __hip_atomic_store(f1, 1, MAGMA_RLX_AGENT);
+  }
+}
+
+__device__ __forceinline__ void abandon(int* info) {
+  if (threadIdx.x == 0) __hip_atomic_store(info, -999, MAGMA_RLX_AGENT);
+}
+
+#ifdef MAGMA_DAG_STAMPS
+#define DAG_STAMP(t, s)                                                          \
+  do {                                                                           \
+    if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(t) * 8 + (s)] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define DAG_STAMP(t, s) do { } while (0)
+#endif
+
+constexpr int DAG_LDS_V = 64 * TLD;  // staged tile (V / result / the diagonal block's S and X)
+
+__global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
+  __shared__ __attribute__((aligned(16))) double Vs[DAG_LDS_V];
+  __shared__ __attribute__((aligned(16))) double As[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  __shared__ __attribute__((aligned(16))) double Pn[512];
+  __shared__ __attribute__((aligned(16))) double Xch[1024];
+  __shared__ int s_ticket;
+  __shared__ int s_ready;
+  static_assert(64 * 65 <= DAG_LDS_V, "diagonal block staging must fit");
+  const int nt = a.nt, ld = a.ld;
+  const unsigned bytes = (unsigned)ld * (unsigned)ld * 8u;
+  const rsrc_t rL = make_rsrc(a.L, bytes), rU = make_rsrc(a.U, bytes);
+  const int ntri = nt * (nt + 1) / 2;
+  const int total = nt * nt + ntri;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) {
+      int t = atomicAdd(a.ctrl, 1);
+      if (__hip_atomic_load(a.ctrl + 1, MAGMA_RLX_AGENT) != 0) t = total;
+      s_ticket = t;
+    }
+    __syncthreads();
+    const int t = s_ticket;
+    __syncthreads();
+    if (t >= total) return;
+    DAG_STAMP(t, 0);
+    TileAcc acc;
+    tile_zero(acc);
+    if (t >= nt * nt) {
+      // ---- I(i,j): rows i <= nt-1 in order, so the longest sums start first
+      const int p = t - nt * nt;
+      int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+      while (i * (i + 1) / 2 > p) --i;
+      while ((i + 1) * (i + 2) / 2 <= p) ++i;
+      const int j = p - i * (i + 1) / 2;
+      if (!acc_rows(rU, (unsigned)i * NB, a.fU + i * nt, rU, (unsigned)j * NB, a.fU + j * nt, i, nt,
+                    ld, acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      double* C = a.Aout + (int64_t)i * NB + (int64_t)j * NB * ld;
+      double* Ct = a.Aout + (int64_t)j * NB + (int64_t)i * NB * ld;
+      const bool diag = (i == j);
+      DAG_STAMP(t, 1);
+      tile_foreach(acc, [&](int m, int n, double v) {
+        C[m + (int64_t)n * ld] = v;
+        if (!diag) Ct[n + (int64_t)m * ld] = v;
+      });
+      DAG_STAMP(t, 4);
+      continue;
+    }
+    const int j = t / nt, r = t - j * nt;
+    if (r == 0) {
+      // ---- F(j,j)
+      tile_load_neg(acc, a.A + (int64_t)j * NB * (ld + 1), ld);
+      if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)j * NB, a.fL + j * nt, 0, j,
+                    ld, acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      DAG_STAMP(t, 1);
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Vs[m * 65 + n] = -v; });
+      __syncthreads();
+      DAG_STAMP(t, 2);
+      const int lane = tid & 63, wave = tid >> 6;
+      const int l = lane & 15, g = lane >> 4;
+      if (wave == 0) {
+        v4d S[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
+              S[it][jt][v] = (rr >= cc) ? Vs[rr * 65 + cc] : Vs[cc * 65 + rr];
+            }
+        double pm = 1.0;
+        int pe = 0, bad = 0;
+        chol64_factor(S, Pn, Xch, lane, pm, pe, bad);
+        if (lane == 0) {
+          // steps are ordered by the flag chain, so the adds arrive in step order
+          atomicAdd(a.logdet, log(pm) + (double)pe * 0.69314718055994530941723212145818);
+          if (bad != 0) atomicCAS(a.info, 0, j * NB + bad);
+        }
+        __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
+      } else if (wave == 1) {
+        v4d B[4][4];
+        chol64_solve(B, Pn + 256, Xch, lane);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
+              Vs[cc * TLD + rr] = (jt <= it) ? B[it][jt][v] : 0.0;  // X(rr, cc), column cc
+            }
+      } else {
+        chol64_idle();
+        __syncthreads();
+      }
+      __syncthreads();
+      DAG_STAMP(t, 3);
+      // X_jj -> diagonal tile of L (columns contiguous); U_jj = X_jj^T -> diagonal tile of U
+      store_tile_sc1(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), ld);
+      {
+        const int m2 = (tid & 31) * 2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int n = c * 8 + (tid >> 5);  // U(m, n) = X(n, m)
+          double2 u;
+          u.x = Vs[m2 * TLD + n];
+          u.y = Vs[(m2 + 1) * TLD + n];
+          v4u v;
+          __builtin_memcpy(&v, &u, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              v, rU, ((unsigned)j * NB * (unsigned)(ld + 1) + m2 + (unsigned)n * (unsigned)ld) * 8u,
+              0, AUX_SC1);
+        }
+      }
+      publish(a.fL + j * nt + j, a.fU + j * nt + j);
+      DAG_STAMP(t, 4);
+      __syncthreads();
+      continue;
+    }
+    const bool isF = r < nt - j;
+    unsigned offOut;
+    rsrc_t rOut;
+    int* flag;
+    if (isF) {
+      // ---- F(i,j), i > j
+      const int i = j + r;
+      tile_load_neg(acc, a.A + (int64_t)i * NB + (int64_t)j * NB * ld, ld);
+      if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)j * NB, a.fL + j * nt, 0, j,
+                    ld, acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
+      offOut = (unsigned)i * NB + (unsigned)j * NB * (unsigned)ld;
+      rOut = rL;
+      flag = a.fL + i * nt + j;
+    } else {
+      // ---- T(c,j), c < j
+      const int c = r - (nt - j);
+      if (!acc_rows(rU, (unsigned)c * NB, a.fU + c * nt, rL, (unsigned)j * NB, a.fL + j * nt, c, j,
+                    ld, acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
+      offOut = (unsigned)c * NB + (unsigned)j * NB * (unsigned)ld;
+      rOut = rU;
+      flag = a.fU + c * nt + j;
+    }
+    DAG_STAMP(t, 1);
+    TileAcc out;
+    tile_zero(out);
+    if (!times_xt(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), a.fL + j * nt + j, ld, out, Bs,
+                  a.ctrl, &s_ready, a.stamps ? a.stamps + t * 8 + 2 : nullptr))
+      return abandon(a.info);
+    DAG_STAMP(t, 3);
+    __syncthreads();  // every wavefront has read Vs
+    tile_foreach(out, [&](int m, int n, double v) { Vs[n * TLD + m] = v; });
+    __syncthreads();
+    store_tile_sc1(Vs, rOut, offOut, ld);
+    publish(flag, nullptr);
+    DAG_STAMP(t, 4);
+    __syncthreads();
+  }
+}
+
+size_t spd_inverse_dag_ctrl_bytes(int nt) {
+  return (((size_t)(4 + 2 * nt * nt) * sizeof(int)) + 255) & ~(size_t)255;
+}
+
+static int g_dag_workgroups = 256;
+static long long* g_dag_stamps = nullptr;
+void set_dag_workgroups(int v) { g_dag_workgroups = v; }
+void set_dag_stamps(void* p) { g_dag_stamps = static_cast<long long*>(p); }
+
+bool spd_inverse_dag_supported(int Np) {
+  return (size_t)Np * Np * 8 < ((size_t)1 << 32) && g_dag_workgroups > 0;
+}
+
+// work: 3 Np^2 doubles (L, U, control block at the head of the third).
+int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double* work,
+                           hipStream_t st) {
+  const int nt = Np / NB;
+  const size_t n2 = (size_t)Np * Np;
+  DagArgs a;
+  a.A = A;
+  a.Aout = A;
+  a.L = work;
+  a.U = work + n2;
+  int* ctrl = reinterpret_cast<int*>(work + 2 * n2);
+  a.ctrl = ctrl;
+  a.fL = ctrl + 4;
+  a.fU = ctrl + 4 + nt * nt;
+  a.logdet = logdet;
+  a.info = info;
+  a.stamps = g_dag_stamps;
+  a.nt = nt;
+  a.ld = Np;
+  if (spd_inverse_dag_ctrl_bytes(nt) > n2 * sizeof(double))
+    return fail(2, "spd_inverse: workspace too small for the control block");
+  MAGMA_CHECK_HIP(hipMemsetAsync(ctrl, 0, spd_inverse_dag_ctrl_bytes(nt), st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+  const int total = nt * nt + nt * (nt + 1) / 2;
+  const int grid = total < g_dag_workgroups ? total : g_dag_workgroups;
+  hipLaunchKernelGGL(spd_inverse_dag_kernel, dim3(grid), dim3(256), 0, st, a);
+  return check_hip(hipGetLastError(), "spd_inverse_dag");
+}
+
+}  // namespace magma

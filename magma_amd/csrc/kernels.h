@@ -39,6 +39,14 @@ size_t spd_inverse_workspace_doubles(int Np);
 // A: in = SPD (lower triangle read), out = full symmetric inverse. logdet/info: device scalars.
 int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* work,
                        hipStream_t st);
+// The same as ONE launch of persistent workgroups walking the tile dependency graph
+// (dense_dag.hip); used by launch_spd_inverse when enabled ("dag_workgroups" > 0) and Np^2
+// doubles fit 32-bit byte offsets.
+bool spd_inverse_dag_supported(int Np);
+void set_dag_workgroups(int v);
+void set_dag_stamps(void* p);  // diagnostic builds only (-DMAGMA_DAG_STAMPS)
+int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double* work,
+                           hipStream_t st);
 int launch_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,
                    const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                    hipStream_t st);

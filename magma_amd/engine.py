@@ -454,6 +454,9 @@ class Engine:
             os.environ.get("MAGMA_MSTEP", "resident")]
         # workgroups of the resident kernel while the theta_0 chain runs next to it (0 = no cap)
         self.resident_wg_cap = int(os.environ.get("MAGMA_RESIDENT_WGS", 0))
+        # workgroups of the one-launch dense inverse (library default 256; 0 = launch-per-step path)
+        if os.environ.get("MAGMA_DAG_WGS") is not None:
+            _lib.call("magma_set_option", b"dag_workgroups", int(os.environ["MAGMA_DAG_WGS"]))
 
     # ------------------------------------------------------------ E-step (CF:371-395)
     def e_step(self, theta0, theta_i, pen_diag, m0):

@@ -68,8 +68,18 @@ def test_gemm_nt_matches_numpy(gpu):
     assert np.abs(got - exp).max() < 1e-12 * np.abs(exp).max()
 
 
-@pytest.mark.parametrize("N", [1, 37, 64, 65, 200, 450])
-def test_spd_inverse_and_logdet(gpu, N):
+# dag_workgroups: 256 = the one-launch tile-graph inverse (default), 3 = the same with fewer
+# workgroups than tasks in flight (its ticket order must not need co-residency), 0 = the
+# launch-per-step path it replaced.
+@pytest.fixture(params=[256, 3, 0], ids=["dag256", "dag3", "launches"])
+def inverse_path(request, gpu):
+    gpu["_lib"].call("magma_set_option", b"dag_workgroups", C.c_long(request.param))
+    yield request.param
+    gpu["_lib"].call("magma_set_option", b"dag_workgroups", C.c_long(256))
+
+
+@pytest.mark.parametrize("N", [1, 37, 64, 65, 200, 450, 1100])
+def test_spd_inverse_and_logdet(gpu, inverse_path, N):
     torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
     rng = np.random.default_rng(N)
     X = rng.normal(size=(N, N + 5))
@@ -93,11 +103,11 @@ def test_spd_inverse_and_logdet(gpu, N):
     assert np.abs(got - got.T).max() == 0.0  # mirrored store: exactly symmetric
 
 
-def test_spd_inverse_flags_indefinite(gpu):
+@pytest.mark.parametrize("N,bad", [(70, 40), (300, 130)])
+def test_spd_inverse_flags_indefinite(gpu, inverse_path, N, bad):
     torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
-    N = 70
-    A = np.eye(N)
-    A[40, 40] = -1.0
+    A = np.eye(N) + 0.01 * np.ones((N, N))
+    A[bad, bad] = -1.0
     Np = lib.magma_pad(N)
     dA = torch.empty(Np * Np, dtype=torch.float64, device="cuda")
     src = torch.from_numpy(A.T.copy()).cuda()
@@ -107,7 +117,7 @@ def test_spd_inverse_flags_indefinite(gpu):
     ld = torch.zeros(1, dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     _lib.call("magma_spd_inverse", N, _p(dA), _p(ld), _p(info), _p(work), st)
-    assert int(info.item()) == 41
+    assert int(info.item()) == bad + 1
 
 
 # ---------------------------------------------------------------- covariance builders
