@@ -160,6 +160,19 @@ int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, co
 int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,
                       const double* mean, const double* m0, const double* cov, int want_grad,
                       void* work, double* h_out3, int* h_info, void* stream);
+/* m_step's theta_0 problem (CF:412-413: opm(old theta_0, logL_GP_mod, gr_GP_mod, db = mean,
+ * mean = m_0, kern_0, new_cov = cov, pen_diag, method "L-BFGS-B")) run natively: the L-BFGS-B of
+ * magma_lbfgsb_* (one problem, two parameters) around magma_theta0_eval, without a trip through
+ * the host language per evaluation. h_theta0[2]: starting point. Host outputs: h_theta_out[2],
+ * and optionally h_f_out (objective at the result), h_f_x0 (objective at the starting point),
+ * h_iters, h_nfev, h_status (as magma_lbfgsb_result). A trial point whose K_0 is not positive
+ * definite counts as a failed evaluation (f = NaN). Synchronises; the workspace's K_0^-1 is that
+ * of the last trial point afterwards. */
+int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double pen_diag,
+                       const double* mean, const double* m0, const double* cov, int m,
+                       double factr, double pgtol, int maxit, void* work, double* h_theta_out,
+                       double* h_f_out, double* h_f_x0, int* h_iters, int* h_nfev, int* h_status,
+                       void* stream);
 /* Sum of n doubles (deterministic order) -> h_out on the host. Synchronises. */
 int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream);
 

@@ -398,6 +398,37 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
   return 0;
 }
 
+int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double pen_diag,
+                       const double* mean, const double* m0, const double* cov, int m,
+                       double factr, double pgtol, int maxit, void* work, double* h_theta_out,
+                       double* h_f_out, double* h_f_x0, int* h_iters, int* h_nfev, int* h_status,
+                       void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  if (!h_theta0 || !h_theta_out) return fail(2, "theta0_mstep: NULL argument");
+  magma_lbfgsb* opt = magma_lbfgsb_create(1, 2, h_theta0, m, factr, pgtol, maxit);
+  if (!opt) return fail(2, "theta0_mstep: could not create the optimiser");
+  int rc = 0;
+  bool first = true;
+  for (;;) {
+    double x[2];
+    unsigned char active = 0;
+    int nact = 0;
+    if ((rc = magma_lbfgsb_ask(opt, x, &active, &nact)) || nact == 0) break;
+    double out3[3] = {0.0, 0.0, 0.0};
+    int info = 0;
+    if ((rc = magma_theta0_eval(N, grid, x[0], x[1], pen_diag, mean, m0, cov, 1, work, out3, &info,
+                                stream)))
+      break;
+    const double f = (info == 0) ? out3[0] : __builtin_nan("");  // not SPD: as a failed evaluation
+    if (first && h_f_x0) *h_f_x0 = f;
+    first = false;
+    if ((rc = magma_lbfgsb_tell(opt, &f, out3 + 1))) break;
+  }
+  if (!rc) rc = magma_lbfgsb_result(opt, h_theta_out, h_f_out, h_iters, h_nfev, h_status);
+  magma_lbfgsb_destroy(opt);
+  return rc;
+}
+
 int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream) {
   if (n < 0) return fail(2, "n must be >= 0");
   double* w = static_cast<double*>(work);  // needs >= 1025 doubles

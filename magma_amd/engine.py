@@ -373,6 +373,22 @@ class HipBackend:
         f = out[0] if info.value == 0 else float("nan")
         return f, np.array([out[1], out[2]]), info.value
 
+    def theta0_mstep(self, theta0, pen_diag, m=5, factr=1e7, pgtol=0.0, maxit=100):
+        """m_step's theta_0 problem (CF:412-413) as one native call (magma_theta0_mstep): the
+        optimiser loop around theta0_eval runs in the library. Returns minimize_batch's dict."""
+        x0 = (C.c_double * 2)(float(theta0[0]), float(theta0[1]))
+        x, f, fx0 = (C.c_double * 2)(), C.c_double(0.0), C.c_double(0.0)
+        it, nf, st = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.call("magma_theta0_mstep", self.N, _ptr(self.grid), x0, float(pen_diag),
+                  _ptr(self.mean), _ptr(self.m0), _ptr(self.cov), int(m), float(factr),
+                  float(pgtol), int(maxit), _ptr(self.work), x, C.byref(f), C.byref(fx0),
+                  C.byref(it), C.byref(nf), C.byref(st), self.stream())
+        self._a0_key = None  # the workspace holds K_0^-1 of the last TRIAL point
+        return {"x": np.array([[x[0], x[1]]]), "f": np.array([f.value]),
+                "f_x0": np.array([fx0.value]), "iters": np.array([it.value], dtype=np.int32),
+                "nfev": np.array([nf.value], dtype=np.int32),
+                "status": np.array([st.value], dtype=np.int32)}
+
     # -- results back to the host
     def get_mean(self):
         return self.mean[:self.N].cpu().numpy()
@@ -507,6 +523,10 @@ class Engine:
             return np.array([f]), g[None, :]
 
         def run0():
+            if hasattr(self.be, "theta0_mstep") and self.native_mstep:
+                r = self.be.theta0_mstep(theta0, pen_diag, **kw)
+                self.stats["theta0_evals"] += int(r["nfev"][0])
+                return r
             return minimize_batch(np.asarray(theta0, dtype=np.float64)[None, :], ev0, **kw)
         # theta_0 (few dense N x N evaluations, small grids) and the theta_i problems (many
         # wide launches with host round trips) are independent given the E-step: run theta_0
