@@ -28,7 +28,7 @@ int check_hip(hipError_t e, const char* what) {
 
 // Carve-up of the caller-provided dense workspace (all offsets in doubles).
 struct Work {
-  double *A0, *T, *inv, *z, *alpha, *tmp, *partials, *scal;
+  double *A0, *T, *inv, *Z, *z, *alpha, *tmp, *partials, *scal;
   int* iinfo;
   Work(void* base, int Np) {
     const size_t n2 = (size_t)Np * Np;
@@ -37,6 +37,8 @@ struct Work {
     A0 = p; p += n2;
     T = p; p += n2;
     inv = p; p += 3 * n2;
+    Z = p; p += n2;  // lower tiles of T K_0^-1 (never the inverse's L / U area: its tiles are
+                     // handed between workgroups with write-through stores and sc1 loads only)
     z = p; p += Np;
     alpha = p; p += Np;
     tmp = p; p += Np;
@@ -47,7 +49,7 @@ struct Work {
   static size_t bytes(int Np) {
     const size_t n2 = (size_t)Np * Np;
     const int nt = Np / 64;
-    return sizeof(double) * (5 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
+    return sizeof(double) * (6 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
   }
 };
 
@@ -386,7 +388,7 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
     }
     Prof pf(PROF_CONTRACT, st);
     if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2,
-                                     wk.partials, wk.scal + 3, st)))
+                                     wk.Z, wk.partials, wk.scal + 3, st)))
       return rc;
   }
   if ((rc = launch_theta0_finish(N, Np, wk.scal, wk.scal + 8, want_grad, st))) return rc;

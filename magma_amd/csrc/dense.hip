@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void lauum_kernel(const double* __restrict__ U
 }
 
 // ------------------------------------------------------------------ general C = alpha A B^T + beta C
-__global__ __launch_bounds__(256) void gemm_nt_kernel(int K, double alpha,
+__global__ __launch_bounds__(256, 8) void gemm_nt_kernel(int K, double alpha,
                                                       const double* __restrict__ A, int64_t lda,
                                                       const double* __restrict__ B, int64_t ldb,
                                                       double beta, double* __restrict__ C,
@@ -493,14 +493,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int K, double alpha,
 }
 
 // ------------------------------------------------------------------ theta_0 gradient contraction
-// Z = T Kinv (never stored), W = alpha alpha' + Z - Kinv, partial sums over the true N x N
-// region of sum(W o K_nl) and sum(W o dK/dtheta2); lower tiles only (off-diagonal tiles x2).
-__global__ __launch_bounds__(256) void theta0_contract_kernel(
-    int N, int Np, const double* __restrict__ T, const double* __restrict__ Kinv,
-    const double* __restrict__ alpha, const double* __restrict__ grid, double th1, double th2,
-    double* __restrict__ partials) {
+// W = alpha alpha' + Z - Kinv with Z = T Kinv, contracted with K_nl and dK/dtheta2 over the true
+// N x N region; lower tiles only (off-diagonal tiles x2). Two launches: the product of the lower
+// tiles into a scratch matrix (16 MB at N = 2000: a few microseconds of HBM time) and an
+// element-wise pass. Both are held to 64 registers per lane (8 waves per SIMD), like
+// gemm_nt_kernel: the theta_0 chain runs next to the device-resident M-step, whose wavefronts
+// hold 448 registers each; a 64-register wavefront still fits beside one on the same SIMD and
+// uses the MFMA cycles it leaves idle instead of waiting for a whole SIMD to retire (a fused
+// product + epilogue kernel needs 108 registers and took 1.0 ms there against 0.2 ms alone).
+__global__ __launch_bounds__(256, 8) void gemm_nt_lower_kernel(int K, const double* __restrict__ A,
+                                                               int64_t lda,
+                                                               const double* __restrict__ B,
+                                                               int64_t ldb, double* __restrict__ C,
+                                                               int64_t ldc) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
+  if (blockIdx.y > blockIdx.x) return;
+  TileAcc acc;
+  tile_zero(acc);
+  tile_gemm_nt(A + (int64_t)blockIdx.x * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc,
+               As, Bs);
+  double* Ct = C + (int64_t)blockIdx.x * NB + (int64_t)blockIdx.y * NB * ldc;
+  tile_foreach(acc, [&](int m, int n, double v) { Ct[m + (int64_t)n * ldc] = v; });
+}
+
+__global__ __launch_bounds__(256, 8) void theta0_contract_kernel(
+    int N, int Np, const double* __restrict__ Z, const double* __restrict__ Kinv,
+    const double* __restrict__ alpha, const double* __restrict__ grid, double th1, double th2,
+    double* __restrict__ partials) {
   __shared__ double red[2][4];
   const int i = blockIdx.x, j = blockIdx.y, nt = gridDim.x;
   double* out = partials + 2 * ((int64_t)j * nt + i);
@@ -512,27 +532,28 @@ __global__ __launch_bounds__(256) void theta0_contract_kernel(
     return;
   }
   const int64_t ld = Np;
-  TileAcc acc;
-  tile_zero(acc);
-  tile_gemm_nt(T + (int64_t)i * NB, ld, Kinv + (int64_t)j * NB, ld, Np / 16, acc, As, Bs);
   const double h = 0.5 * exp(-th2);
   const double eth1 = exp(th1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gm = i * NB + lane;
+  const double am = alpha[gm], tm = grid[gm];
   double s1 = 0.0, s2 = 0.0;
-  tile_foreach(acc, [&](int m, int n, double v) {
-    const int gm = i * NB + m, gn = j * NB + n;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int gn = j * NB + wave + 4 * r;
     if (gm < N && gn < N) {
-      const double W = v + alpha[gm] * alpha[gn] - Kinv[gm + (int64_t)gn * ld];
-      const double d = grid[gm] - grid[gn];
+      const int64_t o = gm + (int64_t)gn * ld;
+      const double W = Z[o] + am * alpha[gn] - Kinv[o];
+      const double d = tm - grid[gn];
       const double gq = h * d * d;
       const double knl = (gm == gn) ? eth1 : exp(th1 - gq);
       s1 += W * knl;
       s2 += W * knl * gq;
     }
-  });
+  }
   const double wgt = (i == j) ? 1.0 : 2.0;
   s1 = wave_sum(s1) * wgt;
   s2 = wave_sum(s2) * wgt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wave] = s1;
     red[1][wave] = s2;
@@ -749,9 +770,11 @@ int launch_dot(int64_t n, const double* a, const double* b, double* partial, dou
 
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
-                           double* partials, double* out2, hipStream_t st) {
+                           double* Z, double* partials, double* out2, hipStream_t st) {
   const int nt = Np / NB;
-  hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, T, Kinv, alpha,
+  hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(nt, nt), dim3(256), 0, st, Np, T, (int64_t)Np, Kinv,
+                     (int64_t)Np, Z, (int64_t)Np);
+  hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, Kinv, alpha,
                      grid, th1, th2, partials);
   hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
                      out2);

@@ -480,8 +480,13 @@ __device__ __forceinline__ void indiv_eval_body(
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-          cor = fma(Ks[(4 * kk + g) * LD + 16 * jt + l], cf[kk][jt], cor);
+        for (int jt = 0; jt < NT; ++jt) {
+          // columns >= NMAX of the last tile column read the next row / the unwritten tail of
+          // Ks: selected away (a product with the zero padding of C would turn a stale NaN
+          // bit pattern left in LDS by another kernel into a NaN result)
+          const double kv = Ks[(4 * kk + g) * LD + 16 * jt + l];
+          cor = fma((16 * jt + 15 < NMAX || 16 * jt + l < NMAX) ? kv : 0.0, cf[kk][jt], cor);
+        }
       cor = wave_sum(cor);
     }
     STAMP(3);
