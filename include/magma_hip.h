@@ -192,6 +192,12 @@ int magma_copy_pad(int N, const double* src, int64_t ld_src, double* dst, int ze
                    void* stream);
 int magma_copy_unpad(int N, const double* src, double* dst, int64_t ld_dst, void* stream);
 
+/* Test aid, no counterpart in the reference: fills the LDS of every compute unit with NaN bit
+ * patterns (workgroups of the maximum LDS size, a few per CU), so that a kernel whose result
+ * depends on LDS it never wrote shows up as a NaN in the parity tests instead of once in a
+ * while. Synchronises. */
+int magma_debug_poison_lds(void* stream);
+
 /* ---- batched L-BFGS-B driver (host side, reverse communication) ----
  * Stands in for `optimr::opm(method = "L-BFGS-B")` -> stats::optim (CF:412-413, 417-418,
  * 426-429; MG:93-94) with its defaults (lmm 5, factr 1e7, pgtol 0, maxit 100, no bounds),

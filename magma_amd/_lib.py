@@ -48,6 +48,7 @@ SIGNATURES = {
     "magma_theta0_mstep": (_i, [_i, _p, C.POINTER(_d), _d, _p, _p, _p, _i, _d, _d, _i, _p,
                                 C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i),
                                 C.POINTER(_i), C.POINTER(_i), _p]),
+    "magma_debug_poison_lds": (_i, [_p]),
     "magma_sum": (_i, [_i64, _p, _p, C.POINTER(_d), _p]),
     "magma_pred_gp": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "magma_gemm_nt": (_i, [_i, _i, _i, _d, _p, _i64, _p, _i64, _d, _p, _i64, _p]),

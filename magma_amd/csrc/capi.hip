@@ -431,6 +431,15 @@ int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double
   return rc;
 }
 
+int magma_debug_poison_lds(void* stream) {
+  double* sink = nullptr;
+  MAGMA_CHECK_HIP(hipMalloc((void**)&sink, sizeof(double)));
+  int rc = launch_poison_lds(sink, S(stream));
+  if (!rc) rc = check_hip(hipStreamSynchronize(S(stream)), "poison_lds sync");
+  (void)hipFree(sink);
+  return rc;
+}
+
 int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream) {
   if (n < 0) return fail(2, "n must be >= 0");
   double* w = static_cast<double*>(work);  // needs >= 1025 doubles

@@ -615,6 +615,18 @@ __global__ void fill_kernel(int64_t n, double v, double* __restrict__ x) {
     x[e] = v;
 }
 
+// Test aid (magma_debug_poison_lds): every word of the workgroup's LDS becomes a NaN pattern.
+__global__ __launch_bounds__(256) void poison_lds_kernel(int ndoubles, double* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) double pl[];
+  const double nanv = __longlong_as_double(0x7ff8dead7ff8deadLL);
+  for (int e = threadIdx.x; e < ndoubles; e += 256) pl[e] = nanv;
+  __syncthreads();
+  // keep the stores alive, and the workgroup on its CU long enough for the grid to spread
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(16);
+  if (threadIdx.x == 0 && pl[(blockIdx.x * 7) % ndoubles] == 0.0) sink[0] = 1.0;
+}
+
 // out[0] = sum_e a[e] b[e] over n elements (deterministic two-stage: per-block partials in
 // `scratch`, then one block). Used for z'alpha (vectors) and sum(Kinv o C) (N x N region).
 __global__ __launch_bounds__(256) void dot_stage1_kernel(int64_t n, const double* __restrict__ a,
@@ -756,6 +768,21 @@ int launch_axpy(int64_t n, double alpha, const double* x, double* yio, hipStream
 int launch_fill(int64_t n, double v, double* x, hipStream_t st) {
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, v, x);
   return check_hip(hipGetLastError(), "fill");
+}
+
+int launch_poison_lds(double* sink, hipStream_t st) {
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (int rc = check_hip(hipGetDevice(&dev), "poison_lds")) return rc;
+  if (int rc = check_hip(hipGetDeviceProperties(&prop, dev), "poison_lds")) return rc;
+  const size_t bytes = prop.sharedMemPerBlock & ~(size_t)15;  // largest workgroup allocation
+  if (int rc = check_hip(hipFuncSetAttribute((const void*)poison_lds_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)bytes), "poison_lds"))
+    return rc;
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(prop.multiProcessorCount * 4), dim3(256), bytes, st,
+                     (int)(bytes / 8), sink);
+  return check_hip(hipGetLastError(), "poison_lds");
 }
 
 // partial: >= 1024 doubles of scratch

@@ -58,6 +58,7 @@ int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
                            double* Z, double* partials, double* out2, hipStream_t st);
 int launch_fill(int64_t n, double v, double* x, hipStream_t st);
+int launch_poison_lds(double* sink, hipStream_t st);
 int launch_set_identity_pad(int N, int Np, double* A, hipStream_t st);
 int launch_copy_pad(int N, int Np, const double* src, int64_t lds, double* dst, int zero_pad,
                     hipStream_t st);

@@ -542,6 +542,7 @@ class Engine:
                 return np.array([f]), g[None, :]
             rc = minimize_batch(theta_i[0][None, :], evc, **kw)
             self.last_sum_fi = float(rc["f_x0"][0])  # already summed over ranks
+            self.last_sum_fi_new = float(rc["f"][0])
             par = self.comm.bcast_host(rc["x"][0], like=like)
             new_theta_i = np.tile(par, (theta_i.shape[0], 1))
         else:
@@ -559,10 +560,11 @@ class Engine:
                     self.stats["indiv_rounds"] += ri["rounds"]
                 else:
                     ri = minimize_batch(theta_i[self.lo:self.hi], evi, **kw)
-                loc, fsum = ri["x"], float(np.sum(ri["f_x0"]))
+                loc, fsum, fnew = ri["x"], float(np.sum(ri["f_x0"])), float(np.sum(ri["f"]))
             else:
-                loc, fsum = np.zeros((0, 3)), 0.0
-            self.last_sum_fi = float(self.comm.allreduce_host(np.array([fsum]), like=like)[0])
+                loc, fsum, fnew = np.zeros((0, 3)), 0.0, 0.0
+            tot = self.comm.allreduce_host(np.array([fsum, fnew]), like=like)
+            self.last_sum_fi, self.last_sum_fi_new = float(tot[0]), float(tot[1])
             new_theta_i = self.comm.allgather_rows(loc, self.counts, like=like)
         if fut0 is not None:
             r0 = fut0()
@@ -583,7 +585,13 @@ class Engine:
         # E-step's K_0^-1 (same theta_0, same pen_diag = mean sigma_i: CF:251, 381) and its
         # individual terms are the optimisers' first evaluations at the old theta_i.
         l_old = -self.last_f0 - self.last_sum_fi
-        l_new = self.logL_monitoring(new_theta0, new_theta_i)
+        # logL_monitoring(new hp) (MG:60): its individual terms are the optimisers' objective
+        # values at the points they returned (same mean, cov); only the theta_0 term needs an
+        # evaluation (pen_diag changes from mean 2 sigma_i to mean sigma_i of the new hp), and
+        # that one leaves K_0^-1 behind for the next E-step.
+        sig = float(new_theta_i[:, 2].mean())
+        ll_0, _ = self.f0(new_theta0, sig, want_grad=False)
+        l_new = -ll_0 - self.last_sum_fi_new
         return new_theta0, new_theta_i, l_old, l_new
 
     def training(self, prior_mean, ini_theta0, ini_theta_i, common_hp=True, n_loop_max=25,

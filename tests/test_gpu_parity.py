@@ -350,3 +350,42 @@ def test_resident_mstep_equals_lock_step_mstep(gpu):
     assert np.abs(a["x"] - b["x"]).max() <= 1e-12 * max(1.0, np.abs(b["x"]).max())
     assert np.abs(a["f_x0"] - b["f_x0"]).max() <= 1e-12 * np.abs(b["f_x0"]).max()
     assert np.abs(a["f"] - b["f"]).max() <= 1e-12 * np.abs(b["f"]).max()
+
+
+def test_results_do_not_depend_on_stale_lds(gpu):
+    """LDS is not cleared between workgroups. Every kernel's padding tricks (identity padding,
+    fragment reads that run past a row, zero-padded operands) must select stale words away, never
+    multiply them by zero: with the LDS of every CU filled with NaN patterns first, the parity
+    tests above must still pass. (Found as a sporadic NaN of the f-only evaluation.)"""
+    _lib = gpu["_lib"]
+
+    def poison():
+        _lib.call("magma_debug_poison_lds", _stream(gpu["torch"]))
+    cases = [
+        (test_kern_to_cov_and_inv_batched, ([1, 2, 3, 7, 8, 9, 30, 31, 33, 50, 64],)),
+        (test_e_step_matches_oracle, ([1, 5, 17, 40, 64, 12, 3],)),
+        (test_logL_GP_mod_and_gradient_per_individual, ([1, 2, 12, 30, 50, 64],)),
+        (test_theta0_objective_and_gradient, ()),
+        (test_common_hp_objective_and_monitoring, ()),
+        (test_pred_gp_matches_oracle, ()),
+        (test_spd_inverse_and_logdet, (256, 200)),
+        (test_em_iteration_shortcuts_equal_explicit_monitoring, ()),
+        (test_resident_mstep_equals_lock_step_mstep, ()),
+    ]
+    for fn, args in cases:
+        poison()
+        fn(gpu, *args)
+    # the f-only evaluation on its own, many times over (the kernel that showed it)
+    from magma_amd.engine import Dataset, Engine
+    rng = np.random.default_rng(31)
+    db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 50, 1])
+    ds = Dataset(db)
+    eng = Engine(ds)
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+    eng.e_step(np.array([1.0, 1.0]), thi, 0.2, 0.4)
+    ref, _ = eng.be.indiv_eval(thi, False)
+    assert np.all(np.isfinite(ref))
+    for _ in range(20):
+        poison()
+        f, _ = eng.be.indiv_eval(thi, False)
+        assert np.array_equal(f, ref)
