@@ -32,33 +32,39 @@ class Dataset:
         ids_col = np.asarray(db["ID"])
         t_col = np.asarray(db["Timestamp"], dtype=np.float64)
         y_col = np.asarray(db["Output"], dtype=np.float64)
-        self.ids = list(unique_in_order(ids_col)) if ids_col.size else []
-        ts, ys, off = [], [], [0]
-        for i in self.ids:
-            sel = np.nonzero(ids_col == i)[0]
-            order = np.argsort(t_col[sel], kind="stable")
-            ts.append(t_col[sel][order])
-            ys.append(y_col[sel][order])
-            off.append(off[-1] + sel.size)
+        # One grouping pass, O(R log R) in the number of rows: individuals in order
+        # of first appearance (`unique(db$ID)`), rows of an individual by timestamp. Replaces a
+        # `filter(ID == i)` scan per individual, which is O(M R).
+        if ids_col.size:
+            uniq, first, inv = np.unique(ids_col, return_index=True, return_inverse=True)
+            rank = np.empty(uniq.size, dtype=np.int64)
+            rank[np.argsort(first, kind="stable")] = np.arange(uniq.size)
+            grp = rank[inv.ravel()]
+            order = np.lexsort((t_col, grp))  # stable: ties keep db order
+            self.ids = list(uniq[np.argsort(first, kind="stable")])
+            counts = np.bincount(grp, minlength=uniq.size)
+            self.t = np.ascontiguousarray(t_col[order])
+            self.y = np.ascontiguousarray(y_col[order])
+            g_sorted = grp[order]
+        else:
+            self.ids, counts = [], np.zeros(0, dtype=np.int64)
+            self.t, self.y, g_sorted = np.zeros(0), np.zeros(0), np.zeros(0, dtype=np.int64)
         self.M = len(self.ids)
-        self.off = np.asarray(off, dtype=np.int64)
-        self.t = np.concatenate(ts) if ts else np.zeros(0)
-        self.y = np.concatenate(ys) if ys else np.zeros(0)
+        self.off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         pieces = [self.t]
         if extra_timestamps is not None:
             pieces.append(np.asarray(extra_timestamps, dtype=np.float64).ravel())
         self.grid = np.unique(np.concatenate(pieces))
         self.N = int(self.grid.size)
         self.idx = np.searchsorted(self.grid, self.t).astype(np.int32)
-        n = np.diff(self.off)
-        self.nmax = int(n.max()) if n.size else 1
+        self.nmax = int(counts.max()) if counts.size else 1
         if self.nmax > N_SMALL_MAX:
             raise ValueError(f"an individual has {self.nmax} observations; the HIP path handles "
                              f"n_i <= {N_SMALL_MAX} (one wavefront per individual)")
-        for i in range(self.M):
-            ti = self.t[self.off[i]:self.off[i + 1]]
-            if np.any(np.diff(ti) <= 0):
-                raise ValueError(f"individual {self.ids[i]!r} has duplicated timestamps")
+        dup = (np.diff(self.t) <= 0) & (g_sorted[1:] == g_sorted[:-1])
+        if np.any(dup):
+            bad = self.ids[int(g_sorted[1:][dup][0])]
+            raise ValueError(f"individual {bad!r} has duplicated timestamps")
 
     @classmethod
     def from_arrays(cls, off, t, y, grid=None, ids=None):

@@ -163,3 +163,84 @@ def test_lbfgsb_compact_ask_tell_equals_full_size_ask_tell():
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
     assert np.abs(out[0][0] - ctr).max() < 1e-4
+
+
+# ---------------------------------------------------------------- input layer
+def _loop_grouping(db):
+    """The reference's way: one `filter(ID == i)` scan per individual, timestamps sorted."""
+    ids_col, t_col, y_col = np.asarray(db["ID"]), np.asarray(db["Timestamp"]), np.asarray(db["Output"])
+    ids = list(orc.unique_in_order(ids_col))
+    t, y, off = [], [], [0]
+    for i in ids:
+        sel = np.nonzero(ids_col == i)[0]
+        o = np.argsort(t_col[sel], kind="stable")
+        t.append(t_col[sel][o])
+        y.append(y_col[sel][o])
+        off.append(off[-1] + sel.size)
+    return ids, np.concatenate(t), np.concatenate(y), np.asarray(off)
+
+
+def test_dataset_grouping_equals_per_individual_scans():
+    from magma_amd.engine import Dataset
+    rng = np.random.default_rng(5)
+    sizes = [7, 1, 30, 12, 64, 3]
+    names = ["b10", "a2", "10", "9", "zz", "b1"]  # first-appearance order != sorted order
+    ids = np.concatenate([[nm] * n for nm, n in zip(names, sizes)])
+    t = np.concatenate([rng.choice(np.arange(200) * 0.05, n, replace=False) for n in sizes])
+    y = rng.normal(size=t.size)
+    # interleave the rows of different individuals, keeping each ID's first appearance order
+    perm = np.argsort(rng.random(t.size) + np.repeat(np.arange(len(sizes)), sizes) * 0.3, kind="stable")
+    db = {"ID": ids[perm], "Timestamp": t[perm], "Output": y[perm]}
+    ds = Dataset(db, extra_timestamps=[11.0, 0.05])
+    ids_l, t_l, y_l, off_l = _loop_grouping(db)
+    assert [str(i) for i in ds.ids] == [str(i) for i in ids_l]
+    assert np.array_equal(ds.off, off_l) and np.array_equal(ds.t, t_l) and np.array_equal(ds.y, y_l)
+    assert np.array_equal(ds.grid, np.unique(np.concatenate([t, [11.0, 0.05]])))
+    assert np.array_equal(ds.grid[ds.idx], ds.t) and ds.nmax == 64
+    with pytest.raises(ValueError, match="duplicated"):
+        Dataset({"ID": ["a", "b", "a"], "Timestamp": [1.0, 1.0, 1.0], "Output": [0.0, 0.0, 0.0]})
+    with pytest.raises(ValueError, match="observations"):
+        Dataset({"ID": ["a"] * 65, "Timestamp": np.arange(65.0), "Output": np.zeros(65)})
+    empty = Dataset({"ID": [], "Timestamp": [], "Output": []})
+    assert empty.M == 0 and empty.N == 0
+
+
+def test_dataset_grouping_is_one_pass_at_full_size():
+    """C3's db as a long table (5e5 rows, 1e4 string IDs): seconds, not an O(M R) scan."""
+    import time
+    from magma_amd.engine import Dataset
+    rng = np.random.default_rng(6)
+    M, n = 10000, 50
+    ids = np.repeat(np.array([f"id{k}" for k in range(M)]), n)
+    t = (rng.integers(0, 2000, size=(M, 1)) + np.arange(n)[None, :] * 7) % 2000 * 0.005
+    t = t.reshape(-1)
+    perm = rng.permutation(M * n)
+    t0 = time.perf_counter()
+    ds = Dataset({"ID": ids[perm], "Timestamp": t[perm], "Output": np.zeros(M * n)})
+    dt = time.perf_counter() - t0
+    assert ds.M == M and ds.nmax == n and np.all(np.diff(ds.off) == n)
+    assert dt < 20.0, dt
+
+
+def test_read_csv2_reads_the_reference_format(tmp_path):
+    from magma_amd.io import read_csv2, split_by
+    p = tmp_path / "db.csv"
+    p.write_text("ID;Timestamp;Output;a;b;sigma;ID_dataset\n"
+                 "1; 0,05; 1,091629e+01;0,31;0,86;0,79;  1\n"
+                 "1; 0,20;-1,035429e+01;0,31;0,86;0,79;  1\n"
+                 "12;10,00; 2,5e-03;1,5;0;0,79;  2\n")
+    tb = read_csv2(str(p))
+    assert list(tb) == ["ID", "Timestamp", "Output", "a", "b", "sigma", "ID_dataset"]
+    assert list(tb["ID"]) == ["1", "1", "12"] and list(tb["ID_dataset"]) == ["1", "1", "2"]
+    assert np.array_equal(tb["Timestamp"], [0.05, 0.2, 10.0])
+    assert np.array_equal(tb["Output"], [10.91629, -10.35429, 0.0025])
+    parts = split_by(tb)
+    assert list(parts) == ["1", "2"] and parts["1"]["Output"].size == 2
+    ref = "/root/reference/Simulations/Data/db_rep_100_M_20_N_30_time_FALSE_hp_TRUE.csv"
+    if os.path.exists(ref):  # the reference's own file against the fixture decoded from it
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "data_FT.npz"))
+        tb = read_csv2(ref)
+        assert np.array_equal(tb["ID"].astype(np.int64), gold["ID"])
+        assert np.array_equal(tb["ID_dataset"].astype(np.int64), gold["ID_dataset"])
+        assert np.array_equal(tb["Timestamp"], gold["Timestamp"])
+        assert np.array_equal(tb["Output"], gold["Output"])
