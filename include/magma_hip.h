@@ -184,6 +184,19 @@ int magma_pred_gp(int n, const double* tn, const double* yn, const double* mean_
                   const int* idx_n, int T, const double* ts, const double* mean_pred,
                   const int* idx_t, const double* cov, int N, const double* theta3,
                   double* mean_out, double* var_out, int* d_info, void* stream);
+/* pred_gp (MG:172-180) for B new individuals against ONE hyper-posterior that stays in HBM
+ * (the mean[Np] / cov[Np x Np] that magma_estep_finish left there for posterior_mu, MG:107-133):
+ * what `loop_pred` / `full_algo` (simulation_study.R:262-324, MG:203-242) do per new individual,
+ * in one launch and without moving cov to the host and back. Ragged inputs: individual b has
+ * observations off_n[b]..off_n[b+1] (n_b <= nmax <= 64) and targets off_t[b]..off_t[b+1]
+ * (T_b <= tmax); idx_n / idx_t: positions of those timestamps in the grid of mean / cov (every
+ * timestamp must be on it, as MG:161-176 index by name). theta: (theta1, theta2, sigma) per
+ * individual (theta_stride 3) or shared (0). Outputs ragged like ts; d_info[B] (0 = ok). */
+int magma_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, const double* tn,
+                          const double* yn, const int* idx_n, const int64_t* off_t,
+                          const double* ts, const int* idx_t, const double* mean,
+                          const double* cov, int N, const double* theta, int theta_stride,
+                          double* mean_out, double* var_out, int* d_info, void* stream);
 
 /* ---- dense helpers exposed for tests and for hosts that compose their own pipelines ---- */
 int magma_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t lda,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "magma_debug_poison_lds": (_i, [_p]),
     "magma_sum": (_i, [_i64, _p, _p, C.POINTER(_d), _p]),
     "magma_pred_gp": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "magma_pred_gp_batched": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i,
+                                   _p, _p, _p, _p]),
     "magma_gemm_nt": (_i, [_i, _i, _i, _d, _p, _i64, _p, _i64, _d, _p, _i64, _p]),
     "magma_copy_pad": (_i, [_i, _p, _i64, _p, _i, _p]),
     "magma_copy_unpad": (_i, [_i, _p, _p, _i64, _p]),

@@ -397,6 +397,53 @@ def pred_gp(db, timestamps=None, mean_mu=0.0, cov_mu=None, kern=kernel, theta=(1
     return {"Timestamp": ts, "Mean": o_mean.cpu().numpy(), "Var": o_var.cpu().numpy()}
 
 
+def posterior_mu_resident(db, new_dbs, timestamps, m_0, kern_0, kern_i, hp, pen_diag=0.1):
+    """posterior_mu (MG:107-133) on the union of `timestamps` and the timestamps of EVERY new
+    individual in `new_dbs`, left on the device: returns the Engine holding mean / cov in HBM for
+    `pred_gp_batched`. The hyper-posterior at a timestamp does not depend on which
+    other timestamps the grid holds (a GP posterior is consistent under marginalisation), so this
+    equals the reference's per-individual posterior_mu up to rounding."""
+    _check_kern(kern_0, kern_i)
+    extra = [np.asarray(timestamps, float).ravel()]
+    extra += [np.asarray(nd["Timestamp"], float).ravel() for nd in new_dbs]
+    eng = Engine(Dataset(_as_db(db), extra_timestamps=np.concatenate(extra)), comm=_dist_comm())
+    th0, thi = _hp_arrays(hp, eng.ds.ids)
+    if isinstance(pen_diag, str):
+        pen_diag = float(np.mean(thi[:, 2]))
+    info = eng.e_step(th0, thi, pen_diag, m_0)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"hyper-posterior precision not positive definite ({info})")
+    return eng
+
+
+def pred_gp_batched(eng, new_dbs, timestamps, theta, sigma, kern=kernel):
+    """pred_gp (MG:135-181) for many new individuals against the hyper-posterior resident in
+    `eng` (from posterior_mu_resident): one launch, cov never leaves the device. `timestamps`:
+    one array for all or a list; `theta` [B, 2] or [2], `sigma` [B] or scalar. Returns a list of
+    {Timestamp, Mean, Var} like pred_gp."""
+    _check_kern(kern)
+    B = len(new_dbs)
+    shared = not isinstance(timestamps, (list, tuple))
+    tss = [np.asarray(timestamps if shared else timestamps[b], float).ravel() for b in range(B)]
+    tn, yn, off_n, off_t = [], [], [0], [0]
+    for b, nd in enumerate(new_dbs):
+        t = np.asarray(nd["Timestamp"], dtype=np.float64)
+        o = np.argsort(t, kind="stable")
+        tn.append(t[o])
+        yn.append(np.asarray(nd["Output"], dtype=np.float64)[o])
+        off_n.append(off_n[-1] + t.size)
+        off_t.append(off_t[-1] + tss[b].size)
+    th = np.empty((B, 3))
+    th[:, :2] = np.asarray(theta, dtype=np.float64).reshape(-1, 2)
+    th[:, 2] = np.asarray(sigma, dtype=np.float64).ravel()
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0)  # noqa: E731
+    mean, var, info = eng.be.pred_gp_batched(off_n, cat(tn), cat(yn), off_t, cat(tss), th)
+    if np.any(info != 0):
+        raise np.linalg.LinAlgError("cov_tn_tn not positive definite")
+    return [{"Timestamp": tss[b], "Mean": mean[off_t[b]:off_t[b + 1]],
+             "Var": var[off_t[b]:off_t[b + 1]]} for b in range(B)]
+
+
 def full_algo(db, new_db, timestamps, kern_i, common_hp=True, plot=False, prior_mean=0.0,
               kern_0=None, list_hp=None, mu=None, ini_hp=None, hp_new_i=None, pen_diag=0.1):
     """MG:203-242 (plotting is out of scope: `plot` is accepted and ignored)."""

@@ -462,6 +462,23 @@ int magma_pred_gp(int n, const double* tn, const double* yn, const double* mean_
                         cov ? magma_pad(N) : 0, theta3, mean_out, var_out, d_info, S(stream));
 }
 
+int magma_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, const double* tn,
+                          const double* yn, const int* idx_n, const int64_t* off_t,
+                          const double* ts, const int* idx_t, const double* mean,
+                          const double* cov, int N, const double* theta, int theta_stride,
+                          double* mean_out, double* var_out, int* d_info, void* stream) {
+  if (B < 0) return fail(2, "pred_gp_batched: B must be >= 0");
+  if (nmax < 1 || nmax > MAGMA_NSMALL_MAX) return fail(2, "pred_gp_batched: nmax must be in 1..64");
+  if (tmax < 0 || tmax > 8 * 65535) return fail(2, "pred_gp_batched: tmax must be in 0..524280");
+  if (B > 65535) return fail(2, "pred_gp_batched: at most 65535 individuals per call");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (N < 1 || !mean || !cov || !idx_n || !idx_t)
+    return fail(2, "pred_gp_batched: mean, cov (on one grid of N points) and idx_n / idx_t required");
+  return launch_pred_gp_batched(B, nmax, tmax, off_n, tn, yn, idx_n, off_t, ts, idx_t, mean, cov,
+                                magma_pad(N), theta, theta_stride, mean_out, var_out, d_info,
+                                S(stream));
+}
+
 int magma_prof_enable(int on) {
   g_prof_on = on != 0;
   return 0;

@@ -31,6 +31,11 @@ int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean
                    const int* idx_n, int T, const double* ts, const double* mean_pred,
                    const int* idx_t, const double* cov, int64_t ldc, const double* theta,
                    double* out_mean, double* out_var, int* info, hipStream_t st);
+int launch_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, const double* tn,
+                           const double* yn, const int* idx_n, const int64_t* off_t,
+                           const double* ts, const int* idx_t, const double* mean_grid,
+                           const double* cov, int64_t ldc, const double* theta, int tstride,
+                           double* out_mean, double* out_var, int* info, hipStream_t st);
 
 // ---- dense union-grid (N x N, padded to a multiple of 64, column-major, ld = Np) ----
 int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2, double sigma,

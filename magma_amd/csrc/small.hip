@@ -712,26 +712,38 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
 // One wavefront inverts cov_tn_tn = K(tn) + C[in,in]; each workgroup then handles a chunk
 // of target timestamps: Mean = m_t + k' inv (y - m_obs), Var = (e^th1 + sigma^2 + C[t,t])
 // - k' inv k, with k = kern(tn - t) + C[in, t] (plain kernel, no noise: MG:174).
-template <int NMAX>
-__global__ __launch_bounds__(64) void pred_gp_kernel(
+#define PRED_GP_LDS                                            \
+  __shared__ double tbuf[64];                                  \
+  __shared__ double zbuf[64];                                  \
+  __shared__ double kbuf[64];                                  \
+  __shared__ int ibuf[64];                                     \
+  __shared__ __attribute__((aligned(16))) double colbuf[64]
+
+// mean_grid != nullptr: the mean process is given on cov's grid and gathered through idx_n /
+// idx_t (the device-resident route of the batched entry point); else mean_obs / mean_pred hold it.
+template <int NMAX, bool GRID>
+__device__ __forceinline__ void pred_gp_body(
     int n, const double* __restrict__ tn, const double* __restrict__ yn,
     const double* __restrict__ mean_obs, const int* __restrict__ idx_n, int T,
     const double* __restrict__ ts, const double* __restrict__ mean_pred,
-    const int* __restrict__ idx_t, const double* __restrict__ cov, int64_t ldc,
+    const int* __restrict__ idx_t, const double* __restrict__ mean_grid,
+    const double* __restrict__ cov, int64_t ldc,
     const double* __restrict__ theta, double* __restrict__ out_mean,
-    double* __restrict__ out_var, int* __restrict__ info_out, int chunk) {
-  __shared__ double tbuf[64];
-  __shared__ double zbuf[64];
-  __shared__ double kbuf[64];
-  __shared__ int ibuf[64];
-  __shared__ __attribute__((aligned(16))) double colbuf[64];
+    double* __restrict__ out_var, int* __restrict__ info_out, int chunk_id, int chunk,
+    double* tbuf, double* zbuf, double* kbuf, int* ibuf, double* colbuf) {
   const int lane = threadIdx.x;
   const double sigma = theta[2];
   const SEParams p = se_params(theta[0], theta[1], sigma);
   const bool rv = lane < n;
   const double tr = rv ? tn[lane] : 0.0;
   const int ir = (rv && idx_n) ? idx_n[lane] : 0;
-  const double zr = rv ? (yn[lane] - mean_obs[lane]) : 0.0;
+  double mo = 0.0;
+  if constexpr (GRID) {
+    if (rv) mo = mean_grid[ir];
+  } else {
+    if (rv) mo = mean_obs[lane];
+  }
+  const double zr = rv ? (yn[lane] - mo) : 0.0;
   tbuf[lane] = tr;
   zbuf[lane] = zr;
   ibuf[lane] = ir;
@@ -747,11 +759,11 @@ __global__ __launch_bounds__(64) void pred_gp_kernel(
   double logdet;
   int info;
   sweep_inverse<NMAX>(a, lane, colbuf, logdet, info);
-  if (lane == 0 && blockIdx.x == 0) info_out[0] = info;
+  if (lane == 0 && chunk_id == 0) info_out[0] = info;
   double alpha = 0.0;
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) alpha = fma(a[c], zbuf[c], alpha);
-  const int j0 = blockIdx.x * chunk;
+  const int j0 = chunk_id * chunk;
   const int j1 = min(T, j0 + chunk);
   for (int j = j0; j < j1; ++j) {
     const double tt = ts[j];
@@ -769,10 +781,48 @@ __global__ __launch_bounds__(64) void pred_gp_kernel(
     const double m = wave_sum(kv * alpha);
     if (lane == 0) {
       const double ctt = (cov != nullptr) ? cov[(int64_t)it * ldc + it] : 0.0;
-      out_mean[j] = mean_pred[j] + m;
+      double mp;
+      if constexpr (GRID) mp = mean_grid[it]; else mp = mean_pred[j];
+      out_mean[j] = mp + m;
       out_var[j] = (p.eth1 + p.sig2 + ctt) - q;
     }
   }
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(64) void pred_gp_kernel(
+    int n, const double* __restrict__ tn, const double* __restrict__ yn,
+    const double* __restrict__ mean_obs, const int* __restrict__ idx_n, int T,
+    const double* __restrict__ ts, const double* __restrict__ mean_pred,
+    const int* __restrict__ idx_t, const double* __restrict__ cov, int64_t ldc,
+    const double* __restrict__ theta, double* __restrict__ out_mean,
+    double* __restrict__ out_var, int* __restrict__ info_out, int chunk) {
+  PRED_GP_LDS;
+  pred_gp_body<NMAX, false>(n, tn, yn, mean_obs, idx_n, T, ts, mean_pred, idx_t, nullptr, cov, ldc, theta,
+                     out_mean, out_var, info_out, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, colbuf);
+}
+
+// pred_gp for B new individuals against ONE device-resident hyper-posterior (the
+// step after training, `loop_pred` / `full_algo` per new individual): workgroup (chunk, b)
+// handles `chunk` targets of individual b. mean / cov stay in HBM where posterior_mu left them;
+// only the ragged observations, targets and their grid positions come in.
+template <int NMAX>
+__global__ __launch_bounds__(64) void pred_gp_batched_kernel(
+    const int64_t* __restrict__ off_n, const double* __restrict__ tn,
+    const double* __restrict__ yn, const int* __restrict__ idx_n,
+    const int64_t* __restrict__ off_t, const double* __restrict__ ts,
+    const int* __restrict__ idx_t, const double* __restrict__ mean_grid,
+    const double* __restrict__ cov, int64_t ldc, const double* __restrict__ theta, int tstride,
+    double* __restrict__ out_mean, double* __restrict__ out_var, int* __restrict__ info_out,
+    int chunk) {
+  PRED_GP_LDS;
+  const int b = blockIdx.y;
+  const int64_t on = off_n[b], ot = off_t[b];
+  const int n = (int)(off_n[b + 1] - on), T = (int)(off_t[b + 1] - ot);
+  if ((int)blockIdx.x * chunk >= T && blockIdx.x != 0) return;  // (chunk 0 always reports info)
+  pred_gp_body<NMAX, true>(n, tn + on, yn + on, nullptr, idx_n + on, T, ts + ot, nullptr, idx_t + ot,
+                     mean_grid, cov, ldc, theta + (int64_t)b * tstride, out_mean + ot, out_var + ot,
+                     info_out + b, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, colbuf);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -920,6 +970,23 @@ int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean
   MAGMA_DISPATCH_NMAX(n, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "pred_gp");
+}
+
+int launch_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, const double* tn,
+                           const double* yn, const int* idx_n, const int64_t* off_t,
+                           const double* ts, const int* idx_t, const double* mean_grid,
+                           const double* cov, int64_t ldc, const double* theta, int tstride,
+                           double* out_mean, double* out_var, int* info, hipStream_t st) {
+  if (B <= 0) return 0;
+  const int chunk = 8;
+  const int gx = tmax > 0 ? (tmax + chunk - 1) / chunk : 1;
+#define CALL(NM)                                                                               \
+  hipLaunchKernelGGL(pred_gp_batched_kernel<NM>, dim3(gx, B), dim3(64), 0, st, off_n, tn, yn,  \
+                     idx_n, off_t, ts, idx_t, mean_grid, cov, ldc, theta, tstride, out_mean,   \
+                     out_var, info, chunk)
+  MAGMA_DISPATCH_NMAX(nmax, CALL);
+#undef CALL
+  return check_hip(hipGetLastError(), "pred_gp_batched");
 }
 
 }  // namespace magma

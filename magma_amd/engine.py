@@ -395,6 +395,46 @@ class HipBackend:
                 "nfev": np.array([nf.value], dtype=np.int32),
                 "status": np.array([st.value], dtype=np.int32)}
 
+    def pred_gp_batched(self, off_n, tn, yn, off_t, ts, theta):
+        """pred_gp (MG:172-180) for B new individuals against the hyper-posterior resident in
+        this backend (mean / cov as estep_finish left them), one launch (magma_pred_gp_batched).
+        Ragged host arrays; every timestamp must lie on this backend's grid. theta: [B, 3] or [3].
+        Returns (mean, var, info[B]) as host arrays, ragged like ts."""
+        torch = self.torch
+        off_n = np.ascontiguousarray(off_n, dtype=np.int64)
+        off_t = np.ascontiguousarray(off_t, dtype=np.int64)
+        B = off_n.size - 1
+        tn = np.ascontiguousarray(tn, dtype=np.float64)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        if B == 0:
+            return np.zeros(0), np.zeros(0), np.zeros(0, dtype=np.int32)
+        grid = self.grid[:self.N].cpu().numpy()
+
+        def on_grid(x):
+            pos = np.minimum(np.searchsorted(grid, x), self.N - 1)
+            if np.any(grid[pos] != x):
+                raise KeyError("subscript out of bounds")  # MG:161-176 index by name
+            return pos.astype(np.int32)
+        i_n, i_t = on_grid(tn), on_grid(ts)
+        nmax, tmax = int(np.diff(off_n).max()), int(np.diff(off_t).max())
+        if nmax > N_SMALL_MAX or int(np.diff(off_n).min()) < 1:
+            raise ValueError("pred_gp_batched: 1 <= n_b <= 64 observations per individual")
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        stride = 0 if th.ndim == 1 else 3
+        assert th.shape == ((3,) if stride == 0 else (B, 3)), th.shape
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
+        d = [up(a) for a in (off_n, tn, np.asarray(yn, dtype=np.float64), i_n, off_t, ts, i_t,
+                             th.reshape(-1))]
+        o_mean = torch.empty(max(ts.size, 1), dtype=torch.float64, device=self.dev)
+        o_var = torch.empty(max(ts.size, 1), dtype=torch.float64, device=self.dev)
+        info = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        _lib.call("magma_pred_gp_batched", B, nmax, tmax, _ptr(d[0]), _ptr(d[1]), _ptr(d[2]),
+                  _ptr(d[3]), _ptr(d[4]), _ptr(d[5]), _ptr(d[6]), _ptr(self.mean), _ptr(self.cov),
+                  self.N, _ptr(d[7]), stride, _ptr(o_mean), _ptr(o_var), _ptr(info),
+                  self.stream())
+        return (o_mean[:ts.size].cpu().numpy(), o_var[:ts.size].cpu().numpy(),
+                info.cpu().numpy())
+
     # -- results back to the host
     def get_mean(self):
         return self.mean[:self.N].cpu().numpy()

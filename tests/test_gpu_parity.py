@@ -389,3 +389,43 @@ def test_results_do_not_depend_on_stale_lds(gpu):
         poison()
         f, _ = eng.be.indiv_eval(thi, False)
         assert np.array_equal(f, ref)
+
+
+def test_pred_gp_batched_matches_oracle_and_single_calls(gpu):
+    """many new individuals predicted in one launch against a device-resident
+    hyper-posterior; against the oracle's posterior_mu + pred_gp and the single-call route."""
+    m = gpu["m"]
+    truth, test, train = dataset("data_FT", 7)
+    hp = hp_of("hp_FT", 7)
+    rng = np.random.default_rng(41)
+    grid_t = np.arange(0.0, 10.0001, 0.05).round(2)
+    new_dbs, tss, thetas, sigmas = [], [], [], []
+    for b, n in enumerate([20, 1, 7, 33, 64, 12]):
+        t = np.sort(rng.choice(grid_t, n, replace=False))
+        perm = rng.permutation(n)  # unsorted input rows, as a db may come
+        new_dbs.append({"Timestamp": t[perm], "Output": (np.sin(t) * 3 + rng.normal(size=n))[perm]})
+        tss.append(np.sort(rng.choice(grid_t, [5, 17, 0, 40, 9, 1][b], replace=False)))
+        thetas.append([rng.uniform(0, 2), rng.uniform(0, 1)])
+        sigmas.append(rng.uniform(0.1, 1.0))
+    eng = m.posterior_mu_resident(train, new_dbs, np.concatenate(tss), 0.0, m.kernel_mu, m.kernel, hp)
+    got = m.pred_gp_batched(eng, new_dbs, tss, np.array(thetas), np.array(sigmas))
+    all_new = {"Timestamp": np.concatenate([d["Timestamp"] for d in new_dbs])}
+    mu = orc.posterior_mu(train, all_new, np.concatenate(tss), 0.0, orc.kernel, orc.kernel, hp)
+    for b, nd in enumerate(new_dbs):
+        assert got[b]["Mean"].size == tss[b].size
+        if tss[b].size == 0:
+            continue
+        o = np.argsort(nd["Timestamp"])
+        db_b = {k: v[o] for k, v in nd.items()}
+        exp = orc.pred_gp(db_b, tss[b], mu["mean"], mu["cov"], orc.kernel, thetas[b], sigmas[b])
+        sc_m, sc_v = np.abs(exp["Mean"]).max(), np.abs(exp["Var"]).max()
+        assert np.abs(got[b]["Mean"] - exp["Mean"]).max() < 1e-8 * max(1.0, sc_m), b
+        assert np.abs(got[b]["Var"] - exp["Var"]).max() < 1e-8 * max(1.0, sc_v), b
+        one = m.pred_gp(db_b, tss[b], mu["mean"], mu["cov"], m.kernel, thetas[b], sigmas[b])
+        assert np.abs(got[b]["Mean"] - one["Mean"]).max() < 1e-8 * max(1.0, sc_m)
+        assert np.abs(got[b]["Var"] - one["Var"]).max() < 1e-8 * max(1.0, sc_v)
+    # shared targets and shared hyper-parameters
+    got2 = m.pred_gp_batched(eng, new_dbs[:2], tss[0], thetas[0], sigmas[0])
+    assert np.array_equal(got2[0]["Mean"], got[0]["Mean"])
+    with pytest.raises(KeyError):
+        m.pred_gp_batched(eng, new_dbs[:1], np.array([0.123]), thetas[0], sigmas[0])
