@@ -37,8 +37,7 @@ struct Work {
     A0 = p; p += n2;
     T = p; p += n2;
     inv = p; p += 3 * n2;
-    Z = p; p += n2;  // lower tiles of T K_0^-1 (never the inverse's L / U area: its tiles are
-                     // handed between workgroups with write-through stores and sc1 loads only)
+    Z = p; p += 2 * n2;  // lower tiles of T K_0^-1, up to two k-slices (theta0_contract_slices)
     z = p; p += Np;
     alpha = p; p += Np;
     tmp = p; p += Np;
@@ -49,7 +48,7 @@ struct Work {
   static size_t bytes(int Np) {
     const size_t n2 = (size_t)Np * Np;
     const int nt = Np / 64;
-    return sizeof(double) * (6 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
+    return sizeof(double) * (7 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
   }
 };
 

@@ -501,26 +501,40 @@ __global__ __launch_bounds__(256, 8) void gemm_nt_kernel(int K, double alpha,
 // hold 448 registers each; a 64-register wavefront still fits beside one on the same SIMD and
 // uses the MFMA cycles it leaves idle instead of waiting for a whole SIMD to retire (a fused
 // product + epilogue kernel needs 108 registers and took 1.0 ms there against 0.2 ms alone).
+// k-slices: slice z of ks sums k in [z K / ks, (z + 1) K / ks) into its own
+// copy of C (C + z * cslice). Half the tiles are skipped, so at N = 2000 one slice per tile leaves
+// two 64-register workgroups per CU, too few to hide their own LDS and barrier latencies
+// (0.27 ms for N^3 flops against 0.28 ms for the full product's 2 N^3); two slices fill the chip.
 __global__ __launch_bounds__(256, 8) void gemm_nt_lower_kernel(int K, const double* __restrict__ A,
                                                                int64_t lda,
                                                                const double* __restrict__ B,
                                                                int64_t ldb, double* __restrict__ C,
-                                                               int64_t ldc) {
+                                                               int64_t ldc, int64_t cslice,
+                                                               int ks) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
-  if (blockIdx.y > blockIdx.x) return;
+  // 1-D grid over (lower tile, slice): consecutive workgroups go to different XCDs, so every XCD
+  // gets the same number of (equal-sized) tasks; a 2-D grid with the upper half skipped gives
+  // XCD x the block rows i = x mod 8, 52 to 80 tiles each.
+  const int z = (int)blockIdx.x % ks, p = (int)blockIdx.x / ks;
+  int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (i * (i + 1) / 2 > p) --i;
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;
+  const int j = p - i * (i + 1) / 2;
+  const int ksl = K / ks;  // multiple of 16 (checked by the launcher)
+  const int64_t k0 = (int64_t)z * ksl;
   TileAcc acc;
   tile_zero(acc);
-  tile_gemm_nt(A + (int64_t)blockIdx.x * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc,
-               As, Bs);
-  double* Ct = C + (int64_t)blockIdx.x * NB + (int64_t)blockIdx.y * NB * ldc;
+  tile_gemm_nt(A + (int64_t)i * NB + k0 * lda, lda, B + (int64_t)j * NB + k0 * ldb, ldb, ksl / 16,
+               acc, As, Bs);
+  double* Ct = C + (int64_t)z * cslice + (int64_t)i * NB + (int64_t)j * NB * ldc;
   tile_foreach(acc, [&](int m, int n, double v) { Ct[m + (int64_t)n * ldc] = v; });
 }
 
 __global__ __launch_bounds__(256, 8) void theta0_contract_kernel(
-    int N, int Np, const double* __restrict__ Z, const double* __restrict__ Kinv,
-    const double* __restrict__ alpha, const double* __restrict__ grid, double th1, double th2,
-    double* __restrict__ partials) {
+    int N, int Np, const double* __restrict__ Z, int zslices, int64_t zslice,
+    const double* __restrict__ Kinv, const double* __restrict__ alpha,
+    const double* __restrict__ grid, double th1, double th2, double* __restrict__ partials) {
   __shared__ double red[2][4];
   const int i = blockIdx.x, j = blockIdx.y, nt = gridDim.x;
   double* out = partials + 2 * ((int64_t)j * nt + i);
@@ -543,7 +557,9 @@ __global__ __launch_bounds__(256, 8) void theta0_contract_kernel(
     const int gn = j * NB + wave + 4 * r;
     if (gm < N && gn < N) {
       const int64_t o = gm + (int64_t)gn * ld;
-      const double W = Z[o] + am * alpha[gn] - Kinv[o];
+      double z = Z[o];
+      for (int q = 1; q < zslices; ++q) z += Z[o + q * zslice];
+      const double W = z + am * alpha[gn] - Kinv[o];
       const double d = tm - grid[gn];
       const double gq = h * d * d;
       const double knl = (gm == gn) ? eth1 : exp(th1 - gq);
@@ -795,14 +811,28 @@ int launch_dot(int64_t n, const double* a, const double* b, double* partial, dou
   return check_hip(hipGetLastError(), "dot");
 }
 
+int theta0_contract_slices(int Np) {
+  const int nt = Np / NB;
+  // two k-slices while one slice per lower tile would leave the chip under ~4 workgroups per CU
+  static const int forced = [] {
+    const char* e = getenv("MAGMA_LOWER_SLICES");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || (forced == 2 && (Np / 16) % 2 == 0)) return forced;
+  return (nt * (nt + 1) / 2 < 1024 && (Np / 16) % 2 == 0) ? 2 : 1;
+}
+
+// Z: theta0_contract_slices(Np) * Np^2 doubles of scratch.
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
                            double* Z, double* partials, double* out2, hipStream_t st) {
   const int nt = Np / NB;
-  hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(nt, nt), dim3(256), 0, st, Np, T, (int64_t)Np, Kinv,
-                     (int64_t)Np, Z, (int64_t)Np);
-  hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, Kinv, alpha,
-                     grid, th1, th2, partials);
+  const int ks = theta0_contract_slices(Np);
+  const int64_t n2 = (int64_t)Np * Np;
+  hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, st, Np, T,
+                     (int64_t)Np, Kinv, (int64_t)Np, Z, (int64_t)Np, n2, ks);
+  hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, ks, n2, Kinv,
+                     alpha, grid, th1, th2, partials);
   hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
                      out2);
   return check_hip(hipGetLastError(), "theta0_contract");
