@@ -13,8 +13,9 @@
 // workgroup that spins on a flag always waits for a workgroup that is already running, whatever
 // the grid size and whatever else occupies the chip (no co-residency assumption):
 //   for j = 0 .. nt-1:
-//     F(j,j)        S = A_jj - sum_{k<j} L_jk L_jk^T;  X_jj = chol(S)^-1, U_jj = X_jj^T
-//     F(i,j), i>j   L_ij = (A_ij - sum_{k<j} L_ik L_jk^T) X_jj^T
+//     D(j)          L_{j,j-1} (as F below), then S = A_jj - sum_{k<j} L_jk L_jk^T;
+//                   X_jj = chol(S)^-1, U_jj = X_jj^T
+//     F(i,j), i>j+1 L_ij = (A_ij - sum_{k<j} L_ik L_jk^T) X_jj^T
 //     T(c,j), c<j   U_cj = -(sum_{c<=k<j} U_ck L_jk^T) X_jj^T        (U = L^-T, upper triangular)
 //   I(i,j), i>=j    Ainv_ij = sum_{k>=i} U_ik U_jk^T, mirrored
 // Hand-off (guide: MI355X_MICROARCH, inter-workgroup visibility, first row of the table): tiles
@@ -111,10 +112,13 @@ __device__ __forceinline__ int poll_ready(const int* fA, const int* fB, int k, i
 // flight: one memory latency per tile, which is what the chain of diagonal tiles sees) and fed
 // to LDS in four 16-column slabs; the next tile's loads are issued under the last slab's MFMAs.
 // Returns false when the launch is being abandoned.
-__device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
-                                         unsigned offB, const int* fB, int k0, int k1, int ld,
-                                         TileAcc& acc, double* As, double* Bs, int* ctrl,
-                                         int* s_ready) {
+// With SELF, accS(m, n) += sum Arow(m, .) Arow(n, .) as well, from the same staged slabs (the
+// diagonal tile of block row A next to its tile in block column B: D(j) below).
+template <bool SELF>
+__device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
+                                           unsigned offB, const int* fB, int k0, int k1, int ld,
+                                           TileAcc& acc, TileAcc& accS, double* As, double* Bs,
+                                           int* ctrl, int* s_ready) {
   if (k0 >= k1) return true;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -159,6 +163,14 @@ __device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA
         acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
         acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
         acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
+        if constexpr (SELF) {
+          const double fs0 = As[kk * TLD + fo + wn * 32];
+          const double fs1 = As[kk * TLD + fo + wn * 32 + 16];
+          accS.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa0, accS.c[0][0], 0, 0, 0);
+          accS.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa1, accS.c[0][1], 0, 0, 0);
+          accS.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa0, accS.c[1][0], 0, 0, 0);
+          accS.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa1, accS.c[1][1], 0, 0, 0);
+        }
       }
     }
     if (more && !pf) {
@@ -168,6 +180,13 @@ __device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA
     }
   }
   return true;
+}
+
+__device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
+                                         unsigned offB, const int* fB, int k0, int k1, int ld,
+                                         TileAcc& acc, double* As, double* Bs, int* ctrl,
+                                         int* s_ready) {
+  return acc_rows_t<false>(ra, offA, fA, rb, offB, fB, k0, k1, ld, acc, acc, As, Bs, ctrl, s_ready);
 }
 
 // out(m, n) = sum_k V(m, k) X(n, k): V staged in LDS as Vs[k * TLD + m] (64 rows of TLD), X = the
@@ -319,15 +338,59 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
     }
     const int j = t / nt, r = t - j * nt;
     if (r == 0) {
-      // ---- F(j,j)
+      // ---- D(j): the tile left of the diagonal, L_{j,j-1}, then F(j,j), by ONE workgroup. The
+      // chain of diagonal tiles runs through L_{j,j-1} (it is the last term of S_jj); computed
+      // here it goes from LDS straight into that term instead of through memory, a flag, a poll
+      // and a fetch (4-5 us of the 24 us a block step took). Both tiles have accumulated all
+      // their earlier terms long before X_{j-1,j-1} appears.
       tile_load_neg(acc, a.A + (int64_t)j * NB * (ld + 1), ld);
-      if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)j * NB, a.fL + j * nt, 0, j,
-                    ld, acc, As, Bs, a.ctrl, &s_ready))
-        return abandon(a.info);
+      if (j > 0) {
+        // both tiles take their terms k < j-1 from the same slabs of block row j, as they appear
+        TileAcc accB;
+        tile_load_neg(accB, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
+        if (!acc_rows_t<true>(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB,
+                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, a.ctrl,
+                              &s_ready))
+          return abandon(a.info);
+        // parked in LDS as the operand of the product with X^T
+        __syncthreads();
+        tile_foreach(accB, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
+      }
+      if (j > 0) {
+        TileAcc out;
+        tile_zero(out);
+        if (!times_xt(Vs, rL, (unsigned)(j - 1) * NB * (unsigned)(ld + 1),
+                      a.fL + (j - 1) * nt + (j - 1), ld, out, Bs, a.ctrl, &s_ready, nullptr))
+          return abandon(a.info);
+        __syncthreads();  // every wavefront has read Vs
+        tile_foreach(out, [&](int m, int n, double v) { Vs[n * TLD + m] = v; });
+        __syncthreads();
+        store_tile_sc1(Vs, rL, (unsigned)j * NB + (unsigned)(j - 1) * NB * (unsigned)ld, ld);
+        {  // acc += L_{j,j-1} L_{j,j-1}^T straight from LDS (Vs[k * TLD + m] = L(m, k))
+          const int lane_ = tid & 63, wave_ = tid >> 6;
+          const int wm = wave_ & 1, wn = wave_ >> 1;
+          const int fo = (lane_ >> 4) * TLD + (lane_ & 15);
+#pragma unroll
+          for (int kk = 0; kk < 64; kk += 4) {
+            const double fa0 = Vs[kk * TLD + fo + wm * 32];
+            const double fa1 = Vs[kk * TLD + fo + wm * 32 + 16];
+            const double fb0 = Vs[kk * TLD + fo + wn * 32];
+            const double fb1 = Vs[kk * TLD + fo + wn * 32 + 16];
+            acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
+            acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
+            acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
+            acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
+          }
+        }
+      }
       DAG_STAMP(t, 1);
-      __syncthreads();
+      __syncthreads();  // (also ends the reads of Vs above)
       tile_foreach(acc, [&](int m, int n, double v) { Vs[m * 65 + n] = -v; });
+      // L_{j,j-1}'s flag goes up here, its stores having drained under the staging of S: nobody
+      // on the chain of diagonal tiles waits for it
+      if (j > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (j > 0 && tid == 0) __hip_atomic_store(a.fL + j * nt + (j - 1), 1, MAGMA_RLX_AGENT);
       DAG_STAMP(t, 2);
       const int lane = tid & 63, wave = tid >> 6;
       const int l = lane & 15, g = lane >> 4;
@@ -393,6 +456,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       continue;
     }
     const bool isF = r < nt - j;
+    if (isF && r == 1) continue;  // L_{j+1,j} belongs to D(j+1)
     unsigned offOut;
     rsrc_t rOut;
     int* flag;
