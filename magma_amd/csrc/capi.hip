@@ -28,7 +28,7 @@ int check_hip(hipError_t e, const char* what) {
 
 // Carve-up of the caller-provided dense workspace (all offsets in doubles).
 struct Work {
-  double *A0, *T, *inv, *Z, *z, *alpha, *tmp, *partials, *scal;
+  double *A0, *T, *inv, *Z, *z, *alpha, *tmp, *partials, *vpart, *scal;
   int* iinfo;
   Work(void* base, int Np) {
     const size_t n2 = (size_t)Np * Np;
@@ -42,13 +42,15 @@ struct Work {
     alpha = p; p += Np;
     tmp = p; p += Np;
     partials = p; p += std::max<size_t>(2 * (size_t)nt * nt, 1024);
+    vpart = p; p += 2 * ((size_t)Np / 4 + 1);
     scal = p; p += 16;
     iinfo = reinterpret_cast<int*>(p);
   }
   static size_t bytes(int Np) {
     const size_t n2 = (size_t)Np * Np;
     const int nt = Np / 64;
-    return sizeof(double) * (7 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) + 16) + 64;
+    return sizeof(double) * (7 * n2 + 3 * (size_t)Np + std::max<size_t>(2 * (size_t)nt * nt, 1024) +
+                            2 * ((size_t)Np / 4 + 1) + 16) + 64;
   }
 };
 
@@ -373,13 +375,8 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
     Prof pf(PROF_SPD_INVERSE, st);
     if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
   }
-  // z = mean - m0 on the true grid, zero on the padding
-  MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, mean, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
-  if ((rc = launch_axpy(Np, -1.0, m0, wk.z, st))) return rc;
-  if (Np > N) MAGMA_CHECK_HIP(hipMemsetAsync(wk.z + N, 0, sizeof(double) * (Np - N), st));
-  if ((rc = launch_symv(Np, wk.A0, wk.z, wk.alpha, st))) return rc;
-  if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
-  if ((rc = launch_dot((int64_t)n2, wk.A0, cov, wk.partials, wk.scal + 2, st))) return rc;
+  // alpha = K_0^-1 (mean - m0), z'alpha and sum(K_0^-1 o cov) in one pass over K_0^-1
+  if ((rc = launch_theta0_vec(N, Np, wk.A0, cov, mean, m0, wk.alpha, wk.vpart, st))) return rc;
   if (want_grad) {
     {
       Prof pf(PROF_GEMM, st);
@@ -387,15 +384,20 @@ int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, d
     }
     Prof pf(PROF_CONTRACT, st);
     if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2,
-                                     wk.Z, wk.partials, wk.scal + 3, st)))
+                                     wk.Z, wk.partials, nullptr, st)))
       return rc;
   }
-  if ((rc = launch_theta0_finish(N, Np, wk.scal, wk.scal + 8, want_grad, st))) return rc;
-  int hinfo = 0;
-  MAGMA_CHECK_HIP(hipMemcpyAsync(h_out3, wk.scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-  MAGMA_CHECK_HIP(hipMemcpyAsync(&hinfo, wk.iinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  // (f, g1, g2, info) in one device-to-host copy
+  if ((rc = launch_theta0_finish2(N, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials,
+                                  want_grad, wk.scal + 8, st)))
+    return rc;
+  double h4[4] = {0.0, 0.0, 0.0, 0.0};
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h4, wk.scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
   MAGMA_CHECK_HIP(hipStreamSynchronize(st));
-  if (h_info) *h_info = hinfo;
+  h_out3[0] = h4[0];
+  h_out3[1] = h4[1];
+  h_out3[2] = h4[2];
+  if (h_info) *h_info = (int)h4[3];
   return 0;
 }
 

@@ -603,6 +603,85 @@ __global__ __launch_bounds__(256) void reduce_pairs_kernel(int64_t n, const doub
   }
 }
 
+// ------------------------------------------------------------------ theta_0 objective, vector part
+// One pass over K_0^-1 for everything the objective needs from it besides the log-det:
+// alpha = K_0^-1 z with z = mean - m0 on the true grid (zero on the padding), z'alpha and
+// sum(K_0^-1 o cov) as per-workgroup partial sums (vpart[2 b], vpart[2 b + 1]); one wavefront per
+// column. Replaces a copy, an axpy, a memset, a symv and two two-stage dot products.
+__global__ __launch_bounds__(256) void theta0_vec_kernel(int N, int Np,
+                                                         const double* __restrict__ Kinv,
+                                                         const double* __restrict__ cov,
+                                                         const double* __restrict__ mean,
+                                                         const double* __restrict__ m0,
+                                                         double* __restrict__ alpha,
+                                                         double* __restrict__ vpart) {
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  double s = 0.0, c = 0.0;
+  if (j < Np) {
+    const double* col = Kinv + (int64_t)j * Np;
+    const double* ccol = cov + (int64_t)j * Np;
+    for (int i = lane; i < Np; i += 64) {
+      const double k = col[i];
+      const double zi = (i < N) ? mean[i] - m0[i] : 0.0;
+      s = fma(k, zi, s);
+      c = fma(k, ccol[i], c);
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if (lane == 0) alpha[j] = s;
+    s *= (j < N) ? mean[j] - m0[j] : 0.0;
+  }
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    vpart[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    vpart[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// out4 = (f, g1, g2, info) from the log-det, the vector part's partial sums and (with want_grad)
+// the contraction's per-tile pairs; one workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void theta0_finish2_kernel(
+    int N, int Np, const double* __restrict__ logdet, const int* __restrict__ info, int nvb,
+    const double* __restrict__ vpart, int64_t npairs, const double* __restrict__ pairs,
+    int want_grad, double* __restrict__ out4) {
+  __shared__ double red[4][4];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < nvb; e += 256) {
+    v[0] += vpart[2 * e];
+    v[1] += vpart[2 * e + 1];
+  }
+  if (want_grad) {
+    for (int64_t e = threadIdx.x; e < npairs; e += 256) {
+      v[2] += pairs[2 * e];
+      v[3] += pairs[2 * e + 1];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = wave_sum(v[q]);
+    if (lane == 0) red[q][wave] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+    // t[1] was summed over the padded Np x Np arrays: each pad diagonal entry adds 1 * 1
+    out4[0] = 0.5 * ((double)N * 1.8378770664093454835606594728112 + logdet[0] + t[0]) +
+              0.5 * (t[1] - (double)(Np - N));
+    out4[1] = want_grad ? -0.5 * t[2] : 0.0;
+    out4[2] = want_grad ? -0.5 * t[3] : 0.0;
+    out4[3] = (double)info[0];
+  }
+}
+
 // ------------------------------------------------------------------ BLAS-1/2 helpers
 // y_j = sum_i A[i + j*ld] x_i  (A symmetric: column j == row j). One wavefront per column.
 __global__ __launch_bounds__(256) void symv_kernel(int Np, const double* __restrict__ A,
@@ -833,9 +912,29 @@ int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                      (int64_t)Np, Kinv, (int64_t)Np, Z, (int64_t)Np, n2, ks);
   hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, ks, n2, Kinv,
                      alpha, grid, th1, th2, partials);
-  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
-                     out2);
+  if (out2 != nullptr)  // (nullptr: the caller sums the per-tile pairs itself)
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
+                       out2);
   return check_hip(hipGetLastError(), "theta0_contract");
+}
+
+int theta0_vec_blocks(int Np) { return (Np + 3) / 4; }
+
+// vpart: 2 * theta0_vec_blocks(Np) doubles.
+int launch_theta0_vec(int N, int Np, const double* Kinv, const double* cov, const double* mean,
+                      const double* m0, double* alpha, double* vpart, hipStream_t st) {
+  hipLaunchKernelGGL(theta0_vec_kernel, dim3(theta0_vec_blocks(Np)), dim3(256), 0, st, N, Np, Kinv,
+                     cov, mean, m0, alpha, vpart);
+  return check_hip(hipGetLastError(), "theta0_vec");
+}
+
+int launch_theta0_finish2(int N, int Np, const double* logdet, const int* info,
+                          const double* vpart, const double* pairs, int want_grad, double* out4,
+                          hipStream_t st) {
+  const int nt = Np / NB;
+  hipLaunchKernelGGL(theta0_finish2_kernel, dim3(1), dim3(256), 0, st, N, Np, logdet, info,
+                     theta0_vec_blocks(Np), vpart, (int64_t)nt * nt, pairs, want_grad, out4);
+  return check_hip(hipGetLastError(), "theta0_finish2");
 }
 
 int launch_set_identity_pad(int N, int Np, double* A, hipStream_t st) {

@@ -62,6 +62,12 @@ int launch_dot(int64_t n, const double* a, const double* b, double* partial, dou
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
                            double* Z, double* partials, double* out2, hipStream_t st);
+int theta0_vec_blocks(int Np);
+int launch_theta0_vec(int N, int Np, const double* Kinv, const double* cov, const double* mean,
+                      const double* m0, double* alpha, double* vpart, hipStream_t st);
+int launch_theta0_finish2(int N, int Np, const double* logdet, const int* info,
+                          const double* vpart, const double* pairs, int want_grad, double* out4,
+                          hipStream_t st);
 int launch_fill(int64_t n, double v, double* x, hipStream_t st);
 int launch_poison_lds(double* sink, hipStream_t st);
 int launch_set_identity_pad(int N, int Np, double* A, hipStream_t st);
