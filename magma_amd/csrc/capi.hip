@@ -195,13 +195,10 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
   if (h_f0) {
     // logL_GP_mod(theta_0; db = new mean, new_cov = new cov, pen_diag) from the K_0^-1 that is
     // still in the workspace: z'K_0^-1 z, log|K_0| and sum(K_0^-1 o cov) -- no factorisation.
-    MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, mean_out, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
-    if ((rc = launch_axpy(Np, -1.0, m0, wk.z, st))) return rc;
-    if (Np > N) MAGMA_CHECK_HIP(hipMemsetAsync(wk.z + N, 0, sizeof(double) * (Np - N), st));
-    if ((rc = launch_symv(Np, wk.A0, wk.z, wk.alpha, st))) return rc;
-    if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
-    if ((rc = launch_dot((int64_t)n2, wk.A0, P, wk.partials, wk.scal + 2, st))) return rc;
-    if ((rc = launch_theta0_finish(N, Np, wk.scal, wk.scal + 8, 0, st))) return rc;
+    if ((rc = launch_theta0_vec(N, Np, wk.A0, P, mean_out, m0, wk.alpha, wk.vpart, st))) return rc;
+    if ((rc = launch_theta0_finish2(N, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials, 0,
+                                    wk.scal + 8, st)))
+      return rc;
     MAGMA_CHECK_HIP(hipMemcpyAsync(h_f0, wk.scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));
   }
   int hinfo[2] = {0, 0};

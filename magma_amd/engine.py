@@ -528,8 +528,8 @@ class Engine:
         P, w = be.estep_scatter(theta_i if common else theta_i[self.lo:self.hi])
         self.comm.allreduce_(P)
         self.comm.allreduce_(w)
-        self.stats["flagged"] += be.n_flagged()
         info, self.last_f0 = be.estep_finish(theta0, pen_diag, want_f0=True)
+        self.stats["flagged"] += be.n_flagged()  # (after the finish: its read-back synchronises)
         return info
 
     # ------------------------------------------------------------ objectives
