@@ -85,6 +85,13 @@ def load():
             raise MagmaHipError(
                 f"{LIB_PATH} not found: build it with `python -m magma_amd.build` "
                 "(there is no CPU fallback for the HIP path)")
+        # torch first: it brings its own HIP runtime, and the device buffers this library is
+        # handed live in that runtime. Loaded before torch, the library would bind the system
+        # runtime instead and see no device ("no ROCm-capable device is detected").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
