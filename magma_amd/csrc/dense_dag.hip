@@ -434,7 +434,9 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       __syncthreads();
       DAG_STAMP(t, 3);
       // X_jj -> diagonal tile of L (columns contiguous); U_jj = X_jj^T -> diagonal tile of U
+      // X_jj first, with its own flag: the next block step waits for X only
       store_tile_sc1(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), ld);
+      publish(a.fL + j * nt + j, nullptr);
       {
         const int m2 = (tid & 31) * 2;
 #pragma unroll
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
               0, AUX_SC1);
         }
       }
-      publish(a.fL + j * nt + j, a.fU + j * nt + j);
+      publish(a.fU + j * nt + j, nullptr);
       DAG_STAMP(t, 4);
       __syncthreads();
       continue;
