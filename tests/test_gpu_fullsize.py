@@ -128,14 +128,16 @@ def test_c2_common_grid_common_hp_matches_oracle(gpu):
     assert np.abs(g - g_o).max() < 1e-8 * np.abs(g_o).max()
 
 
-def test_c4_large_grid_inverse_round_trip(gpu):
-    """Config 4: N = 8,000 union inputs -- dense MFMA Cholesky / inverse at full size, checked
-    by A A^-1 = I with an independent FP64 product (torch), plus the log-det against torch."""
+@pytest.mark.parametrize("N", [4000, 8000], ids=["tile-graph-63-block-rows", "launch-per-step"])
+def test_c4_large_grid_inverse_round_trip(gpu, N):
+    """Config 4: N = 8,000 union inputs -- dense MFMA Cholesky / inverse at full size (the
+    launch-per-step path the library picks above 64 block rows) and N = 4,000 (the largest size
+    of the one-launch tile graph), checked by A A^-1 = I with an independent FP64 product
+    (torch), plus the log-det against torch."""
     torch = gpu
     import ctypes as C
     from magma_amd import _lib
     lib = _lib.load()
-    N = 8000
     Np = lib.magma_pad(N)
     g = torch.linspace(0, 10, N, dtype=torch.float64, device="cuda")
     gp = torch.zeros(Np, dtype=torch.float64, device="cuda")
