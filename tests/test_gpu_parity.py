@@ -429,3 +429,41 @@ def test_pred_gp_batched_matches_oracle_and_single_calls(gpu):
     assert np.array_equal(got2[0]["Mean"], got[0]["Mean"])
     with pytest.raises(KeyError):
         m.pred_gp_batched(eng, new_dbs[:1], np.array([0.123]), thetas[0], sigmas[0])
+
+
+@pytest.mark.parametrize("N", [130, 700, 2000])
+def test_spd_inverse_is_bitwise_repeatable_next_to_other_work(gpu, N):
+    """The one-launch inverse hands tiles between workgroups inside the launch; whichever
+    workgroup takes which task and whatever else occupies the chip, every tile is summed in a
+    fixed order: repeated launches, alone and next to a busy second stream, must agree bit for
+    bit (and never abandon: info == 0)."""
+    torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
+    Np = lib.magma_pad(N)
+    gen = torch.Generator(device="cuda").manual_seed(N)
+    t = torch.sort(torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 10)[0]
+    K = torch.exp(1.0 - 0.5 * np.exp(-1.0) * (t[:, None] - t[None, :]) ** 2) \
+        + 0.3 * torch.eye(N, dtype=torch.float64, device="cuda")
+    A0 = torch.eye(Np, dtype=torch.float64, device="cuda")
+    A0[:N, :N] = K
+    A = A0.clone().reshape(-1)
+    work = torch.empty((lib.magma_workspace_bytes(N) + 7) // 8, dtype=torch.float64, device="cuda")
+    ld = torch.zeros(1, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    big = torch.ones(2048, 2048, dtype=torch.float64, device="cuda")
+    ref = None
+    for it in range(40):
+        A.copy_(A0.reshape(-1))
+        if it % 2 == 1:
+            with torch.cuda.stream(side):
+                big @ big
+        _lib.call("magma_spd_inverse", N, _p(A), _p(ld), _p(info), _p(work), _stream(torch))
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0, (it, int(info.item()))
+        if ref is None:
+            ref = (A.clone(), ld.clone())
+        else:
+            assert torch.equal(A, ref[0]) and torch.equal(ld, ref[1]), it
+    resid = (K @ ref[0].view(Np, Np)[:N, :N]
+             - torch.eye(N, dtype=torch.float64, device="cuda")).abs().max().item()
+    assert resid < 1e-10, resid
