@@ -98,6 +98,18 @@ int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, co
 int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
                        const double* m0, double* P, double* w, double* mean_out, void* work,
                        int reuse_k0inv, double* h_f0, int* h_info, void* stream);
+/* The sums of magma_estep_scatter without atomics (update_inv / update_mean, CF:440-478, in a
+ * fixed order: an E-step is then repeatable bit for bit). K_i^-1 is materialised in Kinv (sum n_i^2
+ * doubles at off2), v = K_i^-1 y_i in v (sum n_i); every element of P / w that receives anything
+ * is out[tgt[k]] = sum of val[src[e]], e in [ptr[k], ptr[k+1]) -- lists the host builds once per
+ * dataset (sources in order of individuals; src indexes Kinv for P and v for w; at most 2^31
+ * sources). P and w must be zero on entry, as for magma_estep_scatter. logdet_scratch: M doubles. */
+int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2, const double* t,
+                       const double* y, const double* theta, int theta_stride, double* Kinv,
+                       double* v, double* logdet_scratch, int64_t ntgt_P, const int64_t* ptr_P,
+                       const int* src_P, const int64_t* tgt_P, int64_t ntgt_w,
+                       const int64_t* ptr_w, const int* src_w, const int64_t* tgt_w, double* P,
+                       double* w, int* info_out, void* stream);
 /* Dense SPD inverse + log-det on its own (solve(), determinant(): CF:27,133,387). A: in =
  * SPD matrix (lower triangle read), out = full symmetric inverse. d_logdet, d_info: device. */
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream);

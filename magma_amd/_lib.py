@@ -35,6 +35,8 @@ SIGNATURES = {
     "magma_kern_to_cov_grid": (_i, [_i, _p, _d, _d, _d, _p, _p]),
     "magma_kern_to_inv_batched": (_i, [_i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "magma_estep_scatter": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "magma_estep_gather": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _i64,
+                                _p, _p, _p, _p, _p, _p, _p]),
     "magma_estep_finish": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _p, _p, _i, C.POINTER(_d),
                                 C.POINTER(_i), _p]),
     "magma_spd_inverse": (_i, [_i, _p, _p, _p, _p, _p]),

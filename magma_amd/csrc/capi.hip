@@ -146,7 +146,7 @@ int magma_kern_to_inv_batched(int M, int nmax, const int64_t* off, const int64_t
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
   Prof pf(PROF_INV_BATCHED, S(stream));
   return launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv_out, logdet_out,
-                               info_out, S(stream));
+                               info_out, nullptr, nullptr, S(stream));
 }
 
 int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
@@ -157,6 +157,25 @@ int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, co
   Prof pf(PROF_SCATTER, S(stream));
   return launch_estep_scatter(M, nmax, off, t, y, idx, theta, theta_stride, P, magma_pad(N), w,
                               info_out, S(stream));
+}
+
+int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2, const double* t,
+                       const double* y, const double* theta, int theta_stride, double* Kinv,
+                       double* v, double* logdet_scratch, int64_t ntgt_P, const int64_t* ptr_P,
+                       const int* src_P, const int64_t* tgt_P, int64_t ntgt_w,
+                       const int64_t* ptr_w, const int* src_w, const int64_t* tgt_w, double* P,
+                       double* w, int* info_out, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (ntgt_P < 0 || ntgt_w < 0) return fail(2, "estep_gather: negative list length");
+  hipStream_t st = S(stream);
+  Prof pf(PROF_SCATTER, st);
+  int rc;
+  if ((rc = launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv, logdet_scratch,
+                                  info_out, y, v, st)))
+    return rc;
+  if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, st))) return rc;
+  return launch_csr_gather_sum(ntgt_w, ptr_w, src_w, tgt_w, v, w, st);
 }
 
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream) {

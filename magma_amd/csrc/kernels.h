@@ -10,7 +10,7 @@ int launch_se_cov_batched(int M, const int64_t* off, const int64_t* off2, const 
                           const double* theta, int tstride, double* out, hipStream_t st);
 int launch_se_inv_batched(int M, int nmax, const int64_t* off, const int64_t* off2,
                           const double* t, const double* theta, int tstride, double* out,
-                          double* logdet, int* info, hipStream_t st);
+                          double* logdet, int* info, const double* y, double* v, hipStream_t st);
 int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
                          const int* idx, const double* theta, int tstride, double* P,
                          int64_t ldp, double* w, int* info, hipStream_t st);
@@ -27,6 +27,8 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
 void set_resident_max_workgroups(int v);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
+int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
+                          const double* val, double* out, hipStream_t st);
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
                    const int* idx_n, int T, const double* ts, const double* mean_pred,
                    const int* idx_t, const double* cov, int64_t ldc, const double* theta,

@@ -198,12 +198,16 @@ __device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParam
 }
 
 // ------------------------------------------------------------------ K1+K3: inverse to HBM
+// With y / v given (the deterministic E-step): v_i = K_i^-1 y_i as well, and a flagged (not
+// positive definite) individual gets zeros in both, since it contributes nothing to the E-step.
 template <int NMAX>
 __global__ __launch_bounds__(64) void se_inv_batched_kernel(
     int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
     const double* __restrict__ t, const double* __restrict__ theta, int tstride,
-    double* __restrict__ out, double* __restrict__ logdet_out, int* __restrict__ info_out) {
+    double* __restrict__ out, double* __restrict__ logdet_out, int* __restrict__ info_out,
+    const double* __restrict__ y, double* __restrict__ v) {
   __shared__ double tbuf[64];
+  __shared__ double ybuf[64];
   extern __shared__ __attribute__((aligned(16))) double Ks[];
   const int i = blockIdx.x, lane = threadIdx.x;
   const int64_t o = off[i];
@@ -211,15 +215,23 @@ __global__ __launch_bounds__(64) void se_inv_batched_kernel(
   const double* th = theta + (int64_t)i * tstride;
   const SEParams p = se_params(th[0], th[1], th[2]);
   tbuf[lane] = (lane < n) ? t[o + lane] : 0.0;
+  ybuf[lane] = (v != nullptr && lane < n) ? y[o + lane] : 0.0;
   __syncthreads();
   double logdet;
   int info;
   se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
   double* Kinv = out + off2[i];
+  const bool zero = (v != nullptr && info != 0);
   if (lane < n) {
+    double s = 0.0;
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
-      if (c < n) Kinv[(int64_t)c * n + lane] = Ks[c * NMAX + lane];
+      if (c < n) {
+        const double k = zero ? 0.0 : Ks[c * NMAX + lane];
+        Kinv[(int64_t)c * n + lane] = k;
+        s = fma(k, ybuf[c], s);
+      }
+    if (v != nullptr) v[o + lane] = s;
   }
   if (lane == 0) {
     logdet_out[i] = logdet;
@@ -296,6 +308,22 @@ __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
       out[e] = (r < n && c < n) ? cov[(int64_t)ibuf[c] * ldc + ibuf[r]] : 0.0;
     }
   }
+}
+
+// ------------------------------------------------------------------ E-step, deterministic route
+// The same sums as estep_scatter_kernel without atomics, so that an E-step is repeatable bit for
+// bit: K_i^-1 and v_i = K_i^-1 y_i materialised by se_inv_batched_kernel (flagged individuals
+// zeroed: they contribute nothing), then every element of P (and of w) that receives
+// anything sums its sources in a fixed order from a list built once per dataset
+// (csr_gather_sum_kernel: out[tgt[k]] = sum_{e in [ptr[k], ptr[k+1])} val[src[e]]).
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(
+    int64_t ntgt, const int64_t* __restrict__ ptr, const int* __restrict__ src,
+    const int64_t* __restrict__ tgt, const double* __restrict__ val, double* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= ntgt) return;
+  double s = 0.0;
+  for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) s += val[src[e]];
+  out[tgt[k]] = s;
 }
 
 // ------------------------------------------------------------------ M-step evaluation
@@ -851,11 +879,11 @@ int launch_se_cov_batched(int M, const int64_t* off, const int64_t* off2, const 
 
 int launch_se_inv_batched(int M, int nmax, const int64_t* off, const int64_t* off2,
                           const double* t, const double* theta, int tstride, double* out,
-                          double* logdet, int* info, hipStream_t st) {
+                          double* logdet, int* info, const double* y, double* v, hipStream_t st) {
   if (M <= 0) return 0;
 #define CALL(NM)                                                                              \
   hipLaunchKernelGGL(se_inv_batched_kernel<NM>, dim3(M), dim3(64), (NM * NM + 16) * sizeof(double), \
-                     st, M, off, off2, t, theta, tstride, out, logdet, info)
+                     st, M, off, off2, t, theta, tstride, out, logdet, info, y, v)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "se_inv_batched");
@@ -871,6 +899,15 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "estep_scatter");
+}
+
+int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
+                          const double* val, double* out, hipStream_t st) {
+  if (ntgt <= 0) return 0;
+  const int64_t grid = (ntgt + 255) / 256;
+  hipLaunchKernelGGL(csr_gather_sum_kernel, dim3((unsigned)grid), dim3(256), 0, st, ntgt, ptr, src,
+                     tgt, val, out);
+  return check_hip(hipGetLastError(), "csr_gather_sum");
 }
 
 template <int NM>

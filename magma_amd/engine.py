@@ -114,6 +114,13 @@ class HipBackend:
         f64, dev = torch.float64, self.dev
         o0, o1 = int(ds.off[lo]), int(ds.off[hi])
         self.n_i = np.diff(ds.off[lo:hi + 1])
+        self._h_off = (ds.off[lo:hi + 1] - o0).astype(np.int64)
+        self._h_idx = ds.idx[o0:o1].copy()
+        # E-step sums: "gather" = fixed summation order (bitwise repeatable E-step, lists built
+        # once per dataset), "atomic" = FP64 atomics straight from the inverting wavefronts
+        import os
+        self.scatter_route = os.environ.get("MAGMA_SCATTER", "gather")
+        self._gl = None
         self.off = torch.from_numpy(ds.off[lo:hi + 1] - o0).to(dev)
         self.t = torch.from_numpy(ds.t[o0:o1].copy()).to(dev)
         self.y = torch.from_numpy(ds.y[o0:o1].copy()).to(dev)
@@ -214,11 +221,59 @@ class HipBackend:
         self._cpack_ok = False
         self.P.zero_()
         self.w.zero_()
-        if self.M > 0:
+        if self.M > 0 and self.scatter_route == "gather":
+            g = self._gather_lists()
+            _lib.call("magma_estep_gather", self.M, self.nmax, _ptr(self.off), _ptr(g["off2"]),
+                      _ptr(self.t), _ptr(self.y), _ptr(self.theta), stride, _ptr(g["Kinv"]),
+                      _ptr(g["v"]), _ptr(self.f), g["nP"], _ptr(g["ptrP"]), _ptr(g["srcP"]),
+                      _ptr(g["tgtP"]), g["nw"], _ptr(g["ptrw"]), _ptr(g["srcw"]), _ptr(g["tgtw"]),
+                      _ptr(self.P), _ptr(self.w), _ptr(self.info), self.stream())
+        elif self.M > 0:
             _lib.call("magma_estep_scatter", self.M, self.nmax, _ptr(self.off), _ptr(self.t),
                       _ptr(self.y), _ptr(self.idx), _ptr(self.theta), stride, self.N,
                       _ptr(self.P), _ptr(self.w), _ptr(self.info), self.stream())
         return self.P, self.w
+
+    def _gather_lists(self):
+        """Source lists of the deterministic E-step (magma_estep_gather), built once per dataset:
+        for every element of the lower triangle of P (every entry of w) that receives anything,
+        the positions of its terms in the materialised K_i^-1 (in v = K_i^-1 y_i), in a fixed
+        order. Replaces the reference's `intersect(row.names)` block updates (CF:440-478)."""
+        if self._gl is not None:
+            return self._gl
+        torch = self.torch
+        off, idx, n = self._h_off, self._h_idx.astype(np.int64), self.n_i.astype(np.int64)
+        off2 = np.concatenate([[0], np.cumsum(n * n)]).astype(np.int64)
+        if off2[-1] >= 2 ** 31:
+            raise ValueError("deterministic E-step: more than 2^31 matrix entries on one rank "
+                             "(set MAGMA_SCATTER=atomic or use more ranks)")
+        tg, sr = [], []
+        for nn in np.unique(n):
+            ids = np.nonzero(n == nn)[0]
+            r, c = np.tril_indices(int(nn))  # r >= c: idx ascending, so the lower triangle of P
+            for a in range(0, ids.size, 8192):  # bounded host temporaries
+                blk = ids[a:a + 8192]
+                o = off[blk][:, None]
+                tg.append((idx[o + r[None, :]] + idx[o + c[None, :]] * self.Np).ravel())
+                sr.append((off2[blk][:, None] + c[None, :] * nn + r[None, :]).ravel())
+        dev = self.dev
+
+        def csr(targets, sources):
+            t = torch.from_numpy(targets).to(dev)
+            ts, perm = torch.sort(t, stable=True)
+            src = torch.from_numpy(sources).to(dev)[perm].to(torch.int32)
+            uniq, counts = torch.unique_consecutive(ts, return_counts=True)
+            ptr = torch.zeros(uniq.numel() + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(counts, 0)
+            return int(uniq.numel()), ptr, src.contiguous(), uniq.contiguous()
+        nP, ptrP, srcP, tgtP = csr(np.concatenate(tg), np.concatenate(sr))
+        nw, ptrw, srcw, tgtw = csr(idx, np.arange(idx.size, dtype=np.int64))
+        f64 = torch.float64
+        self._gl = {"off2": torch.from_numpy(off2).to(dev), "nP": nP, "ptrP": ptrP, "srcP": srcP,
+                    "tgtP": tgtP, "nw": nw, "ptrw": ptrw, "srcw": srcw, "tgtw": tgtw,
+                    "Kinv": torch.empty(max(int(off2[-1]), 1), dtype=f64, device=dev),
+                    "v": torch.empty(max(int(off[-1]), 1), dtype=f64, device=dev)}
+        return self._gl
 
     def n_flagged(self):
         if self.M == 0:

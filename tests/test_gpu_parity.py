@@ -467,3 +467,45 @@ def test_spd_inverse_is_bitwise_repeatable_next_to_other_work(gpu, N):
     resid = (K @ ref[0].view(Np, Np)[:N, :N]
              - torch.eye(N, dtype=torch.float64, device="cuda")).abs().max().item()
     assert resid < 1e-10, resid
+
+
+def test_em_iteration_is_bitwise_repeatable_and_routes_agree(gpu):
+    """Default E-step route ("gather": fixed summation order) makes a whole EM iteration
+    repeatable bit for bit; the atomic route agrees with it to rounding, and both with the
+    oracle (flagged individuals included: they contribute nothing)."""
+    from magma_amd.engine import Dataset, Engine
+    rng = np.random.default_rng(43)
+    db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50])
+    ds = Dataset(db)
+    th0 = np.array([0.9, 0.7])
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1)) + rng.uniform(-0.3, 0.3, size=(ds.M, 3))
+    runs = []
+    for _ in range(2):
+        eng = Engine(ds)
+        assert eng.be.scatter_route == "gather"
+        out = eng.em_iteration(th0, thi, 0.4, False)
+        runs.append((out, eng.be.get_cov(), eng.be.get_mean()))
+    (a, cov_a, mean_a), (b, cov_b, mean_b) = runs
+    assert np.array_equal(cov_a, cov_b) and np.array_equal(mean_a, mean_b)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and a[3] == b[3]
+    eng = Engine(ds)
+    eng.be.scatter_route = "atomic"
+    eng.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.4)
+    cov_at = eng.be.get_cov()
+    eng2 = Engine(ds)
+    eng2.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.4)
+    cov_g = eng2.be.get_cov()
+    assert np.abs(cov_at - cov_g).max() < 1e-12 * np.abs(cov_g).max()
+    # a flagged individual (sigma = 0 and two near-identical timestamps make K_i singular to
+    # rounding -> info != 0) is left out by both routes
+    thi_bad = thi.copy()
+    thi_bad[3] = [5.0, 8.0, 0.0]
+    covs = []
+    for route in ("gather", "atomic"):
+        e = Engine(ds)
+        e.be.scatter_route = route
+        e.e_step(th0, thi_bad, 0.3, 0.4)
+        covs.append((e.be.get_cov(), e.be.n_flagged()))
+    assert covs[0][1] == covs[1][1]
+    assert np.abs(covs[0][0] - covs[1][0]).max() < 1e-12 * np.abs(covs[1][0]).max()
