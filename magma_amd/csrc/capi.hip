@@ -174,8 +174,8 @@ int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2,
   if ((rc = launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv, logdet_scratch,
                                   info_out, y, v, st)))
     return rc;
-  if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, st))) return rc;
-  return launch_csr_gather_sum(ntgt_w, ptr_w, src_w, tgt_w, v, w, st);
+  if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, 0, st))) return rc;
+  return launch_csr_gather_sum(ntgt_w, ptr_w, src_w, tgt_w, v, w, 1, st);
 }
 
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream) {

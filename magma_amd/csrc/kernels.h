@@ -28,7 +28,7 @@ void set_resident_max_workgroups(int v);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
 int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
-                          const double* val, double* out, hipStream_t st);
+                          const double* val, double* out, int wave_per_target, hipStream_t st);
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
                    const int* idx_n, int T, const double* ts, const double* mean_pred,
                    const int* idx_t, const double* cov, int64_t ldc, const double* theta,

@@ -326,6 +326,20 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(
   out[tgt[k]] = s;
 }
 
+// The same for long lists (w: a few hundred sources per grid point): one wavefront per target,
+// lane l adds the sources ptr[k] + l, + 64, ... in order, then a fixed-order wave reduction.
+__global__ __launch_bounds__(256) void csr_gather_sum_wave_kernel(
+    int64_t ntgt, const int64_t* __restrict__ ptr, const int* __restrict__ src,
+    const int64_t* __restrict__ tgt, const double* __restrict__ val, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= ntgt) return;
+  double s = 0.0;
+  for (int64_t e = ptr[k] + lane; e < ptr[k + 1]; e += 64) s += val[src[e]];
+  s = wave_sum(s);
+  if (lane == 0) out[tgt[k]] = s;
+}
+
 // ------------------------------------------------------------------ M-step evaluation
 // mode 0 (logL_GP_mod / gr_GP_mod): K = K(theta, sigma);
 //        f = 1/2 (n log 2pi + log|K| + z'K^-1 z) + 1/2 sum(K^-1 o C),
@@ -902,8 +916,14 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
 }
 
 int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
-                          const double* val, double* out, hipStream_t st) {
+                          const double* val, double* out, int wave_per_target, hipStream_t st) {
   if (ntgt <= 0) return 0;
+  if (wave_per_target) {
+    const int64_t g = (ntgt + 3) / 4;
+    hipLaunchKernelGGL(csr_gather_sum_wave_kernel, dim3((unsigned)g), dim3(256), 0, st, ntgt, ptr,
+                       src, tgt, val, out);
+    return check_hip(hipGetLastError(), "csr_gather_sum_wave");
+  }
   const int64_t grid = (ntgt + 255) / 256;
   hipLaunchKernelGGL(csr_gather_sum_kernel, dim3((unsigned)grid), dim3(256), 0, st, ntgt, ptr, src,
                      tgt, val, out);
