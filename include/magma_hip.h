@@ -102,8 +102,8 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
  * fixed order: an E-step is then repeatable bit for bit). K_i^-1 is materialised in Kinv (sum n_i^2
  * doubles at off2), v = K_i^-1 y_i in v (sum n_i); every element of P / w that receives anything
  * is out[tgt[k]] = sum of val[src[e]], e in [ptr[k], ptr[k+1]) -- lists the host builds once per
- * dataset (sources in order of individuals; src indexes Kinv for P and v for w; at most 2^31
- * sources). P and w must be zero on entry, as for magma_estep_scatter. logdet_scratch: M doubles. */
+ * dataset (any fixed order of sources: it is the order of summation; src indexes Kinv for P and
+ * v for w; at most 2^31 sources). P and w must be zero on entry, as for magma_estep_scatter. logdet_scratch: M doubles. */
 int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2, const double* t,
                        const double* y, const double* theta, int theta_stride, double* Kinv,
                        double* v, double* logdet_scratch, int64_t ntgt_P, const int64_t* ptr_P,
