@@ -53,14 +53,17 @@ def pmc_traffic(kernel_class, evals_per_launch):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                         "r01_pmc_fetch_write.json")
     keys = {"indiv_eval(f+grad)": "magma::indiv_eval_kernel<52>",
-            "indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>"}
+            "indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>",
+            "spd_inverse": "magma::spd_inverse_dag_kernel",
+            "gemm_nt(T=Kinv*C)": "magma::gemm_nt_kernel"}
     if kernel_class not in keys or not os.path.exists(path):
         return None
     with open(path) as fh:
         pmc = json.load(fh)
     key = keys[kernel_class]
     try:
-        if kernel_class == "indiv_mstep(resident)":  # always launched over all M individuals
+        if kernel_class in ("indiv_mstep(resident)", "spd_inverse", "gemm_nt(T=Kinv*C)"):
+            # one fixed-size launch per call: the profiled runs' average is this run's figure
             kb = 2.0 * pmc["FETCH_SIZE"][key]["avg_kb"] + pmc["WRITE_SIZE"][key]["avg_kb"]
             return kb * 1024.0
         kb = 2.0 * pmc["FETCH_SIZE"][key]["kb_per_workgroup_at_max"] \
@@ -223,14 +226,18 @@ def main():
             # Z = T K^-1 is symmetric: only its lower tiles are formed (N^3 executed of the 2 N^3
             # a full product would take); priced on what runs
             "theta0_contract": ("mfma", 1.0 * N ** 3, True),
-            "spd_inverse": ("mfma", 1.0 * N ** 3, False),  # composite: ~75 launches per call
+            # one launch (the tile graph) up to 64 block rows; above that ~75 launches per call
+            "spd_inverse": ("mfma", 1.0 * N ** 3, (N + 63) // 64 <= 64
+                            and os.environ.get("MAGMA_DAG_WGS", "256") != "0"),
             # 5 n^3 flops x the individuals actually evaluated per launch (active list)
             "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * n_evals / ng, True),
             # device-resident M-step: the same 5 n^3 per evaluation, all evaluations of a launch
             "indiv_mstep(resident)": ("mfma", 5.0 * n ** 3 * n_evals / max(1, prof.get(
                 "indiv_mstep(resident)", {}).get("launches", 1)), True),
             "indiv_eval(f)": ("mfma", 1.0 * S3, True),
-            "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n, True),
+            # E-step sums (three launches with the default deterministic route)
+            "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n,
+                              os.environ.get("MAGMA_SCATTER", "gather") == "atomic"),
         }
         for name, (bound, work, single) in alg.items():
             if name in prof:
