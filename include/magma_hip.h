@@ -49,9 +49,11 @@ int magma_memset_zero(void* dst, size_t bytes, void* stream);
 int magma_stream_sync(void* stream);
 
 /* Optional timing of kernel classes with HIP events recorded on the launching stream
- * (bench.py's roofline figures). ids: 0 T = Kinv C GEMM, 1 theta_0 gradient contraction,
- * 2 dense SPD inverse (all its launches), 3 per-individual f + gradient, 4 per-individual f
- * only, 5 E-step scatter, 6 K_0 build, 7 batched K_i build, 8 batched K_i inverse. */
+ * (bench.py's roofline figures). ids: 0 T = Kinv C GEMM, 1 theta_0 gradient contraction
+ * (lower-tile product + element-wise pass), 2 dense SPD inverse (all its launches),
+ * 3 per-individual f + gradient, 4 per-individual f only, 5 E-step sums (scatter, or inverse +
+ * the two gathers), 6 K_0 build, 7 batched K_i build, 8 batched K_i inverse, 9 gather of the
+ * cov blocks (magma_indiv_gather_cov), 10 device-resident per-individual M-step. */
 int magma_prof_enable(int on);
 int magma_prof_reset(void);
 /* Tunables. "resident_max_workgroups": cap on the grid of magma_indiv_mstep_resident (0 = one
@@ -110,6 +112,23 @@ int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2,
                        const int* src_P, const int64_t* tgt_P, int64_t ntgt_w,
                        const int64_t* ptr_w, const int* src_w, const int64_t* tgt_w, double* P,
                        double* w, int* info_out, void* stream);
+/* update_inv (CF:440-455) / update_mean (CF:457-478) on EXPLICIT blocks, for callers that hold
+ * the K_i^-1 themselves (the fused E-step entry points above never materialise them): individual
+ * i's K_i^-1 is n_i x n_i column-major at Kinv + off2[i] (any n_i); P[idx_i, idx_i] += K_i^-1
+ * (the whole block, P = prior_inv as a full Np x Np matrix), w[idx_i] += K_i^-1 y_i (w =
+ * K_0^-1 m_0 on entry). idx < 0 marks a timestamp that is not on the grid: dropped like
+ * `intersect(row.names(...))` drops it (its row/column is not added; K_i^-1 y_i is still formed
+ * from the whole block, CF:468). FP64 atomics. */
+int magma_update_inv(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                     const double* Kinv, int N, double* P, void* stream);
+int magma_update_mean(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                      const double* Kinv, const double* y, int N, double* w, void* stream);
+/* dmvnorm (CF:9-34) with log = TRUE: takes the INVERSE covariance inv_Sigma (Np x Np padded,
+ * identity padding; OVERWRITTEN), x and mu (Np values, equal on the padding). h_out =
+ * -(n log 2pi - log|inv_Sigma| + z' inv_Sigma z) / 2; h_info != 0 (and NaN) when inv_Sigma is
+ * not positive definite. work: magma_workspace_bytes(n). Synchronises. */
+int magma_dmvnorm(int n, const double* x, const double* mu, double* inv_Sigma, void* work,
+                  double* h_out, int* h_info, void* stream);
 /* Dense SPD inverse + log-det on its own (solve(), determinant(): CF:27,133,387). A: in =
  * SPD matrix (lower triangle read), out = full symmetric inverse. d_logdet, d_info: device. */
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream);

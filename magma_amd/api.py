@@ -32,6 +32,17 @@ def kernel_mu(mat, theta=(1.0, 0.5)):
     return np.exp(theta[0] - np.exp(-theta[1]) / 2.0 * np.asarray(mat, float))
 
 
+def deriv_hp1(mat, theta=(1.0, 0.5)):
+    """CF:267-270 (closure passed as `kern` to kern_to_cov by the gradient functions)."""
+    return np.exp(theta[0] - np.exp(-theta[1]) / 2.0 * np.asarray(mat, float))
+
+
+def deriv_hp2(mat, theta=(1.0, 0.5)):
+    """CF:272-277."""
+    grad = 0.5 * np.exp(-theta[1]) * np.asarray(mat, float)
+    return np.exp(theta[0]) * grad * np.exp(-grad)
+
+
 def _check_kern(*kerns):
     for k in kerns:
         if k is not None and k not in (kernel, kernel_mu):
@@ -153,6 +164,101 @@ def _batched_small(db, theta, sigma, inverse):
         res[i] = (ds.t[ds.off[k]:ds.off[k + 1]].copy(),
                   flat[off2[k]:off2[k + 1]].reshape(ni, ni).T.copy())
     return res
+
+
+# ------------------------------------------------------------------ density, E-step pieces
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _padded_matrix(mat, N, Np):
+    """Host [N, N] -> device Np x Np column-major with identity padding."""
+    import torch
+    c = np.eye(Np)
+    c[:N, :N] = mat
+    return torch.from_numpy(np.ascontiguousarray(c.T).reshape(-1)).cuda()
+
+
+def dmvnorm(x, mu, inv_Sigma, log=False):
+    """CF:9-34: Gaussian (log-)density at x given the INVERSE covariance (magma_dmvnorm)."""
+    import torch
+    lib = _lib.load()
+    x = np.asarray(x, dtype=np.float64).ravel()
+    n = x.size
+    mu = np.asarray(mu, dtype=np.float64).ravel()
+    mu = np.full(n, mu[0]) if mu.size == 1 else mu
+    Np = lib.magma_pad(n)
+    pad = lambda v: torch.from_numpy(np.concatenate([v, np.zeros(Np - n)])).cuda()  # noqa: E731
+    d_x, d_mu = pad(x), pad(mu)
+    d_inv = _padded_matrix(np.asarray(inv_Sigma, dtype=np.float64), n, Np)
+    work = torch.empty((lib.magma_workspace_bytes(n) + 7) // 8, dtype=torch.float64, device="cuda")
+    out, info = C.c_double(0.0), C.c_int(0)
+    _lib.call("magma_dmvnorm", n, _ptr(d_x), _ptr(d_mu), _ptr(d_inv), _ptr(work), C.byref(out),
+              C.byref(info), _stream())
+    if info.value != 0:
+        raise np.linalg.LinAlgError(f"inverse covariance not positive definite (info={info.value})")
+    return out.value if log else float(np.exp(out.value))
+
+
+def _explicit_blocks(labels, list_inv_i):
+    """Ragged device layout of a named list of (labels_i, K_i^-1). A timestamp that is not in
+    `labels` gets idx -1: the library drops it like `intersect(row.names(...))` (CF:451,474)."""
+    import torch
+    off, off2, idx, blocks = [0], [0], [], []
+    for lab_i, inv_i in list_inv_i.values():
+        lab_i = np.asarray(lab_i, float)
+        pos = np.minimum(np.searchsorted(labels, lab_i), labels.size - 1)
+        idx.append(np.where(labels[pos] == lab_i, pos, -1).astype(np.int32))
+        blocks.append(np.ascontiguousarray(np.asarray(inv_i, float).T).reshape(-1))
+        off.append(off[-1] + lab_i.size)
+        off2.append(off2[-1] + lab_i.size ** 2)
+    cat = lambda xs, dt: torch.from_numpy(  # noqa: E731
+        np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)).cuda()
+    return (len(blocks), torch.tensor(off, dtype=torch.int64).cuda(),
+            torch.tensor(off2, dtype=torch.int64).cuda(), cat(idx, np.int32),
+            cat(blocks, np.float64))
+
+
+def update_inv(prior_inv, list_inv_i):
+    """CF:440-455: prior_inv = (labels, K_0^-1), list_inv_i = {id: (labels_i, K_i^-1)} ->
+    (labels, K_0^-1 + sum_i scatter(K_i^-1)) (magma_update_inv)."""
+    lib = _lib.load()
+    labels, inv0 = np.asarray(prior_inv[0], float), np.asarray(prior_inv[1], float)
+    N = labels.size
+    Np = lib.magma_pad(N)
+    P = _padded_matrix(inv0, N, Np)
+    M, off, off2, idx, Kinv = _explicit_blocks(labels, list_inv_i)
+    _lib.call("magma_update_inv", M, _ptr(off), _ptr(off2), _ptr(idx), _ptr(Kinv), N, _ptr(P),
+              _stream())
+    return labels, P.view(Np, Np)[:N, :N].t().contiguous().cpu().numpy()
+
+
+def update_mean(prior_mean, prior_inv, list_inv_i, list_value_i):
+    """CF:457-478: K_0^-1 m_0 + sum_i scatter(K_i^-1 y_i) on the grid of prior_inv
+    (magma_update_mean; the prior term is a host product of data the caller already holds)."""
+    import torch
+    lib = _lib.load()
+    labels, inv0 = np.asarray(prior_inv[0], float), np.asarray(prior_inv[1], float)
+    N = labels.size
+    Np = lib.magma_pad(N)
+    pm = np.asarray(prior_mean, float).ravel()
+    pm = np.full(N, pm[0]) if pm.size == 1 else pm
+    # K_0^-1 m_0 through the library's product kernel (m_0 as the first row of a 64-row operand)
+    P = _padded_matrix(inv0, N, Np)
+    B = torch.zeros(Np * 64, dtype=torch.float64, device="cuda")
+    B.view(Np, 64)[:N, 0] = torch.from_numpy(pm).cuda()
+    Cm = torch.empty(64 * Np, dtype=torch.float64, device="cuda")
+    _lib.call("magma_gemm_nt", Np, 64, Np, 1.0, _ptr(P), Np, _ptr(B), 64, 0.0, _ptr(Cm), Np,
+              _stream())
+    w = Cm[:Np].clone()
+    w[N:] = 0.0
+    M, off, off2, idx, Kinv = _explicit_blocks(labels, list_inv_i)
+    ys = [np.asarray(list_value_i[i], float).ravel() for i in list_inv_i]
+    y = torch.from_numpy(np.concatenate(ys) if ys else np.zeros(0)).cuda()
+    _lib.call("magma_update_mean", M, _ptr(off), _ptr(off2), _ptr(idx), _ptr(Kinv), _ptr(y), N,
+              _ptr(w), _stream())
+    return w[:N].cpu().numpy()
 
 
 # ------------------------------------------------------------------ likelihoods / gradients
@@ -305,7 +411,17 @@ def train_new_gp(db, mean_mu, cov_mu, ini_hp_i, kern_i):
     _check_kern(kern_i)
     t = np.asarray(db["Timestamp"], dtype=np.float64)
     if isinstance(mean_mu, dict):
-        mean = np.asarray(mean_mu["Output"], float)[np.isin(mean_mu["Timestamp"], t)]
+        # MG:86-88 `filter(Timestamp %in% db$Timestamp)`: rows in the mean tibble's own (sorted)
+        # order, which is db order only for a db sorted by timestamp (the reference's assumption,
+        # CF:74). Taken in db order here, like new_cov below, so that _indiv_problem permutes
+        # mean, cov and outputs consistently.
+        mt = np.asarray(mean_mu["Timestamp"], float)
+        mo = np.asarray(mean_mu["Output"], float)
+        srt = np.argsort(mt, kind="stable")
+        pos = np.minimum(np.searchsorted(mt[srt], t), mt.size - 1)
+        if np.any(mt[srt][pos] != t):
+            raise KeyError("mean_mu does not cover db$Timestamp")
+        mean = mo[srt][pos]
     else:
         mean = np.asarray(mean_mu, float).ravel()
     if isinstance(cov_mu, tuple):

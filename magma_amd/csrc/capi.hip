@@ -224,6 +224,49 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
   MAGMA_CHECK_HIP(hipMemcpyAsync(hinfo, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   MAGMA_CHECK_HIP(hipStreamSynchronize(st));
   if (h_info) *h_info = hinfo[0] ? hinfo[0] : (hinfo[1] ? -hinfo[1] : 0);
+  // either factorisation failed: mean / cov are garbage, and so is an objective value built on them
+  if (h_f0 && (hinfo[0] || hinfo[1])) *h_f0 = __builtin_nan("");
+  return 0;
+}
+
+int magma_update_inv(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                     const double* Kinv, int N, double* P, void* stream) {
+  if (M < 0) return fail(2, "M must be >= 0");
+  if (N < 1) return fail(2, "N must be >= 1");
+  return launch_update_inv(M, off, off2, idx, Kinv, nullptr, P, magma_pad(N), nullptr, S(stream));
+}
+
+int magma_update_mean(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                      const double* Kinv, const double* y, int N, double* w, void* stream) {
+  if (M < 0) return fail(2, "M must be >= 0");
+  if (N < 1) return fail(2, "N must be >= 1");
+  return launch_update_inv(M, off, off2, idx, Kinv, y, nullptr, magma_pad(N), w, S(stream));
+}
+
+int magma_dmvnorm(int n, const double* x, const double* mu, double* inv_Sigma, void* work,
+                  double* h_out, int* h_info, void* stream) {
+  if (n < 1) return fail(2, "n must be >= 1");
+  if (!h_out) return fail(2, "dmvnorm: h_out is NULL");
+  const int Np = magma_pad(n);
+  hipStream_t st = S(stream);
+  Work wk(work, Np);
+  int rc;
+  // z = x - mu (zero on the padding), ssq = z' Sigma^-1 z
+  MAGMA_CHECK_HIP(hipMemcpyAsync(wk.z, x, sizeof(double) * Np, hipMemcpyDeviceToDevice, st));
+  if ((rc = launch_axpy(Np, -1.0, mu, wk.z, st))) return rc;
+  if ((rc = launch_symv(Np, inv_Sigma, wk.z, wk.alpha, st))) return rc;
+  if ((rc = launch_dot(Np, wk.z, wk.alpha, wk.partials, wk.scal + 1, st))) return rc;
+  // log|Sigma^-1| (CF:27: determinant() of the INVERSE covariance) from the factorisation
+  if ((rc = launch_spd_inverse(Np, inv_Sigma, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  double h2[2] = {0.0, 0.0};
+  int hinfo = 0;
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h2, wk.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipMemcpyAsync(&hinfo, wk.iinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  if (h_info) *h_info = hinfo;
+  const double logdetS = -h2[0];
+  *h_out = hinfo ? __builtin_nan("")
+                 : -((double)n * 1.8378770664093454835606594728112 + logdetS + h2[1]) / 2.0;
   return 0;
 }
 

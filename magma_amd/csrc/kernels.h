@@ -29,6 +29,11 @@ int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
 int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
                           const double* val, double* out, int wave_per_target, hipStream_t st);
+// update_inv / update_mean on explicit K_i^-1 blocks (any n_i): P[idx_i, idx_i] += K_i^-1 (P != null)
+// and / or w[idx_i] += K_i^-1 y_i (w != null), FP64 atomics.
+int launch_update_inv(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                      const double* Kinv, const double* y, double* P, int64_t ldp, double* w,
+                      hipStream_t st);
 int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean_obs,
                    const int* idx_n, int T, const double* ts, const double* mean_pred,
                    const int* idx_t, const double* cov, int64_t ldc, const double* theta,

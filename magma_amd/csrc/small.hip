@@ -23,6 +23,7 @@
 #include "lbfgsb_core.h"
 
 #include <atomic>
+#include <mutex>
 
 namespace magma {
 
@@ -31,6 +32,18 @@ namespace magma {
 #endif
 
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
+
+// Ordering point for LDS traffic WITHIN one wavefront (every per-individual kernel gives an
+// individual to one wavefront, whose LDS region no other wavefront touches): the LDS unit executes
+// a wavefront's instructions in order, so data written by one lane is there for another lane's
+// later read without a hardware barrier; what is needed is that the compiler keeps the two in
+// program order. A workgroup barrier here would tie the four independent wavefronts of the
+// device-resident M-step's workgroups together.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Diagnostic build only (-DMAGMA_STAMPS): cycle shares of the segments of indiv_eval.
 #ifdef MAGMA_STAMPS
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void se_cov_batched_kernel(
 // Build the SE covariance of one individual in accumulator layout (identity padded to NMAX),
 // invert it with the blocked MFMA sweep (mfma_sweep.h; scaled to a unit diagonal first) and
 // leave K^-1 in LDS as Ks[r * NMAX + c] (symmetric). Ks: NMAX * NMAX + 16 doubles, its head
-// doubles as the sweep's transposition buffer. Ends with a barrier.
+// doubles as the sweep's transposition buffer. Ends with a wave_sync().
 template <int NMAX>
 __device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParams& p,
                                                   const double* tbuf, double* Ks, double& logdet,
@@ -194,7 +207,7 @@ __device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParam
         if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
       }
     }
-  __syncthreads();
+  wave_sync();
 }
 
 // ------------------------------------------------------------------ K1+K3: inverse to HBM
@@ -338,6 +351,37 @@ __global__ __launch_bounds__(256) void csr_gather_sum_wave_kernel(
   for (int64_t e = ptr[k] + lane; e < ptr[k + 1]; e += 64) s += val[src[e]];
   s = wave_sum(s);
   if (lane == 0) out[tgt[k]] = s;
+}
+
+// ------------------------------------------------------------------ update_inv / update_mean
+// CF:440-478 on explicit blocks: individual i's K_i^-1 (n_i x n_i, column-major at Kinv + off2[i])
+// is added into P at [idx_i, idx_i] (whole block: P is treated as a full matrix, as the
+// reference does) and K_i^-1 y_i into w at idx_i. A timestamp that is not on the grid (idx < 0)
+// is dropped the way `intersect(row.names(...))` drops it (CF:451, 474): its row and column of
+// K_i^-1 are not added to P; K_i^-1 y_i is still formed from the WHOLE block (CF:468) and only the
+// rows that are on the grid are added to w. Any n_i; one workgroup per individual.
+__global__ __launch_bounds__(256) void update_inv_kernel(
+    int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
+    const int* __restrict__ idx, const double* __restrict__ Kinv, const double* __restrict__ y,
+    double* __restrict__ P, int64_t ldp, double* __restrict__ w) {
+  for (int i = blockIdx.x; i < M; i += gridDim.x) {
+    const int64_t o = off[i];
+    const int n = (int)(off[i + 1] - o);
+    const double* K = Kinv + off2[i];
+    const int* ix = idx + o;
+    if (P != nullptr)
+      for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += blockDim.x) {
+        const int r = ix[(int)(e % n)], c = ix[(int)(e / n)];
+        if (r >= 0 && c >= 0) unsafeAtomicAdd(&P[(int64_t)c * ldp + r], K[e]);
+      }
+    if (w != nullptr)
+      for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        if (ix[r] < 0) continue;
+        double s = 0.0;
+        for (int c = 0; c < n; ++c) s = fma(K[(int64_t)c * n + r], y[o + c], s);
+        unsafeAtomicAdd(&w[ix[r]], s);
+      }
+  }
 }
 
 // ------------------------------------------------------------------ M-step evaluation
@@ -484,7 +528,7 @@ __device__ __forceinline__ void indiv_eval_body(
         if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
       }
     }
-  __syncthreads();
+  wave_sync();
   STAMP(4);
 
   // The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52), issued once the
@@ -541,7 +585,7 @@ __device__ __forceinline__ void indiv_eval_body(
 
   // ---- 4./5. by column block jt: Tc = (C K^-1)[:, jt] (NT tiles), then Z[at][jt] = K^-1 Tc for
   // at >= jt, contracted at once. Only cf (the packed C) stays live across blocks.
-  __syncthreads();  // abuf visible
+  wave_sync();  // abuf visible
   double cor = 0.0;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -681,70 +725,85 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
   lbcore::tell(*st, f, g, factr, pgtol, maxit);
 }
 
+// Workgroups of four wavefronts, each wavefront an independent worker with its own slice of the
+// workgroup's LDS: with ~450 registers per lane a wavefront fills a SIMD's register file, so one
+// workgroup fills one compute unit, and a launch of G workgroups occupies G compute units and
+// leaves the others alone -- which is what the theta_0 chain's dense kernels running next to this
+// one need (the workgroups of the dense inverse want a whole free compute unit; with
+// one-wavefront workgroups spread over every SIMD of the chip they waited for the launch to
+// drain). Individuals are handed out through a ticket counter in the order given (longest
+// expected chain first): a wavefront that finishes a problem takes the next ticket, so the launch
+// lasts max(longest chain, total work / wavefronts).
+constexpr int RES_WAVES = 4;
 template <int NMAX>
-__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_mstep_kernel(
+constexpr int resident_wave_doubles() {
+  return NMAX * NMAX + 16 + 3 * 64 + (int)((sizeof(lbcore::State<3, 5>) + 127) / 128) * 16;
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(224))) void indiv_mstep_kernel(
     int M, const int* __restrict__ order, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ mean, const double* __restrict__ cpack, int mode,
     const double* __restrict__ theta0, int lm,
     double factr, double pgtol, int maxit, double* __restrict__ theta_out,
     double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
-    int* __restrict__ nfev_out, int* __restrict__ status_out) {
-  __shared__ double tbuf[64];
-  __shared__ double zbuf[64];
-  __shared__ double abuf[64];
-  __shared__ lbcore::State<3, 5> st;
-  extern __shared__ __attribute__((aligned(16))) double Ks[];
-  // Grid-stride over the individuals: the launch may be capped to fewer workgroups than
-  // individuals (magma_set_option "resident_max_workgroups") so that these register-file-filling
-  // wavefronts leave SIMDs free for the kernels of other streams.
-  // Slots are taken in `order` when given (longest expected chain first: the launch ends with
-  // its longest chain, so that one should start at time zero).
-  int slot = blockIdx.x;
+    int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket) {
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS bases in SGPRs
+  // this wavefront's LDS: Ks (NMAX^2 + 16; fragment reads of the last rows run up to 12 doubles
+  // past the end, into masked results), timestamps, residuals, alpha, optimiser state
+  double* Ks = dyn + (size_t)wave * resident_wave_doubles<NMAX>();
+  double* tbuf = Ks + NMAX * NMAX + 16;
+  double* zbuf = tbuf + 64;
+  double* abuf = zbuf + 64;
+  lbcore::State<3, 5>* st = reinterpret_cast<lbcore::State<3, 5>*>(abuf + 64);
   int i = 0, n = 0;
   bool fresh = true;
   double fx0 = 0.0;
 #pragma unroll 1
   for (;;) {
     if (fresh) {  // wave-uniform
+      int slot = 0;
+      if ((threadIdx.x & 63) == 0) slot = atomicAdd(ticket, 1);
+      slot = __builtin_amdgcn_readfirstlane(slot);
       if (slot >= M) break;
       i = order ? order[slot] : slot;
-      __syncthreads();
+      wave_sync();
       const int64_t o = off[i];
       n = (int)(off[i + 1] - o);
-      const int lane0 = threadIdx.x;
+      const int lane0 = threadIdx.x & 63;
       const bool rv = lane0 < n;
       tbuf[lane0] = rv ? t[o + lane0] : 0.0;
       zbuf[lane0] = rv ? (y[o + lane0] - mean[idx[o + lane0]]) : 0.0;
-      lbcore::init(st, 3, lm, theta0 + 3 * (int64_t)i);
-      __syncthreads();
+      lbcore::init(*st, 3, lm, theta0 + 3 * (int64_t)i);
+      wave_sync();
       fresh = false;
     }
     // lane is laundered per evaluation: otherwise every lane-derived address and mask of the
     // body is hoisted out of the loop and held in registers across it
-    int lane = threadIdx.x;
+    int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
-    const double th1 = st.xtrial[0], th2 = st.xtrial[1], sigma = st.xtrial[2];
+    const double th1 = st->xtrial[0], th2 = st->xtrial[1], sigma = st->xtrial[2];
     double f, g[3] = {0.0, 0.0, 0.0};
     int info;
     indiv_eval_body<NMAX>(lane, n, i, th1, th2, sigma, tbuf, zbuf, abuf, Ks, cpack, mode, 1, f,
                           g, info);
-    fx0 = (st.nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
-    __syncthreads();  // the body's LDS traffic is over before the state is stepped
-    lbfgsb_tell_device(&st, f, g[0], g[1], g[2], factr, pgtol, maxit);
-    __syncthreads();
-    if (st.status != 0) {
-      if (threadIdx.x == 0) {
+    fx0 = (st->nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
+    wave_sync();  // the body's LDS traffic is over before the state is stepped
+    lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
+    wave_sync();
+    if (st->status != 0) {
+      if ((threadIdx.x & 63) == 0) {
         const double nanv = __longlong_as_double(0x7ff8000000000000LL);
         for (int q = 0; q < 3; ++q)
-          theta_out[3 * (int64_t)i + q] = (st.status == 5) ? nanv : st.x[q];
-        f_out[i] = st.f;
+          theta_out[3 * (int64_t)i + q] = (st->status == 5) ? nanv : st->x[q];
+        f_out[i] = st->f;
         fx0_out[i] = fx0;
-        iters_out[i] = st.iter;
-        nfev_out[i] = st.nfev;
-        status_out[i] = st.status;
+        iters_out[i] = st->iter;
+        nfev_out[i] = st->nfev;
+        status_out[i] = st->status;
       }
-      slot += gridDim.x;
       fresh = true;
     }
   }
@@ -930,6 +989,16 @@ int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, cons
   return check_hip(hipGetLastError(), "csr_gather_sum");
 }
 
+int launch_update_inv(int M, const int64_t* off, const int64_t* off2, const int* idx,
+                      const double* Kinv, const double* y, double* P, int64_t ldp, double* w,
+                      hipStream_t st) {
+  if (M <= 0) return 0;
+  const int grid = M < 65536 ? M : 65536;
+  hipLaunchKernelGGL(update_inv_kernel, dim3(grid), dim3(256), 0, st, M, off, off2, idx, Kinv, y, P,
+                     ldp, w);
+  return check_hip(hipGetLastError(), "update_inv");
+}
+
 template <int NM>
 static int launch_indiv_eval_t(int nsel, const int* sel, const int64_t* off, const double* t,
                                const double* y, const int* idx, const double* theta, int tstride,
@@ -961,9 +1030,48 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
   return rc;
 }
 
-// 0 = one workgroup per individual; > 0 caps the grid of the device-resident M-step.
+// Cap on the workgroups (= compute units) of the device-resident M-step; 0 = every compute unit.
 static std::atomic<int> g_resident_max_wgs{0};
 void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
+
+// Ticket counters of the resident launches: a small ring in device memory, one word per launch
+// (zeroed on the launch's stream), so that launches running at the same time on one GPU -- several
+// engines, several streams -- never share one. A word is reused after RES_TICKETS launches.
+constexpr int RES_TICKETS = 1024;
+static __device__ int g_res_tickets[RES_TICKETS];
+static std::atomic<unsigned> g_res_ticket_next{0};
+
+static int resident_ticket(int** out, hipStream_t st) {
+  static std::mutex mu;
+  static int* base[64] = {nullptr};
+  static int ncu[64] = {0};
+  int dev = 0;
+  if (int rc = check_hip(hipGetDevice(&dev), "indiv_mstep")) return rc;
+  if (dev < 0 || dev >= 64) return fail(2, "indiv_mstep: device index out of range");
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (base[dev] == nullptr) {
+      void* p = nullptr;
+      if (int rc = check_hip(hipGetSymbolAddress(&p, HIP_SYMBOL(g_res_tickets)), "indiv_mstep")) return rc;
+      base[dev] = static_cast<int*>(p);
+    }
+  }
+  (void)ncu;
+  *out = base[dev] + (g_res_ticket_next.fetch_add(1) % RES_TICKETS);
+  return check_hip(hipMemsetAsync(*out, 0, sizeof(int), st), "indiv_mstep ticket");
+}
+
+static int device_compute_units() {
+  static std::atomic<int> cached{0};
+  int v = cached.load();
+  if (v > 0) return v;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+  v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  cached.store(v);
+  return v;
+}
 
 template <int NM>
 static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, const double* t,
@@ -972,19 +1080,25 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
                                 const double* theta0, int lm, double factr, double pgtol,
                                 int maxit, double* theta_out, double* f_out, double* fx0_out,
                                 int* iters, int* nfev, int* status, hipStream_t st) {
-  const size_t dyn = ((size_t)NM * NM + 16) * sizeof(double);
+  const size_t dyn = (size_t)RES_WAVES * resident_wave_doubles<NM>() * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (int rc = check_hip(hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                           "indiv_mstep LDS size"))
+      return rc;
     attr_set = true;
   }
+  int* ticket = nullptr;
+  if (int rc = resident_ticket(&ticket, st)) return rc;
   const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
-  const int grid = (cap > 0 && M > cap) ? cap : M;
-  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64), dyn, st, M, order, off, t, y, idx,
-                     mean,
-                     cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out, fx0_out, iters,
-                     nfev, status);
+  const int cus = device_compute_units();
+  int grid = (M + RES_WAVES - 1) / RES_WAVES;
+  if (grid > cus) grid = cus;  // persistent: one workgroup fills a compute unit
+  if (cap > 0 && grid > cap) grid = cap;
+  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RES_WAVES), dyn, st, M, order, off,
+                     t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out,
+                     fx0_out, iters, nfev, status, ticket);
   return check_hip(hipGetLastError(), "indiv_mstep");
 }
 

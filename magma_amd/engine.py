@@ -158,6 +158,9 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.current_stream(self.dev).synchronize()
 
+    def compute_units(self):
+        return int(self.torch.cuda.get_device_properties(self.dev).multi_processor_count)
+
     def run_aside(self, fn):
         """Run fn() in a helper thread whose HIP work goes to a side stream; returns a join
         function giving fn's result. The caller's stream must already be synchronised with
@@ -569,8 +572,12 @@ class Engine:
         import os
         self.native_mstep = {"resident": "resident", "native": True, "python": False}[
             os.environ.get("MAGMA_MSTEP", "resident")]
-        # workgroups of the resident kernel while the theta_0 chain runs next to it (0 = no cap)
-        self.resident_wg_cap = int(os.environ.get("MAGMA_RESIDENT_WGS", 0))
+        # Compute units kept free of the resident per-individual kernel while the theta_0 chain
+        # runs next to it (its workgroups fill whole compute units; the chain's dense inverse
+        # needs whole free ones): the resident launch is capped at (CUs - reserve) workgroups and
+        # the one-launch inverse at `reserve` for the duration of the M-step. 0 = no split.
+        self.reserve_cus = int(os.environ.get("MAGMA_RESERVE_CUS", 64))
+        self._dag_wgs = int(os.environ.get("MAGMA_DAG_WGS", 256))
         # workgroups of the one-launch dense inverse (library default 256; 0 = launch-per-step path)
         if os.environ.get("MAGMA_DAG_WGS") is not None:
             _lib.call("magma_set_option", b"dag_workgroups", int(os.environ["MAGMA_DAG_WGS"]))
@@ -632,7 +639,15 @@ class Engine:
         # theta_0 (few dense N x N evaluations, small grids) and the theta_i problems (many
         # wide launches with host round trips) are independent given the E-step: run theta_0
         # on a side stream in a helper thread so that the two overlap on the GPU.
-        fut0 = self.be.run_aside(run0) if hasattr(self.be, "run_aside") and not common_hp else None
+        aside = hasattr(self.be, "run_aside") and not common_hp
+        split = (aside and self.reserve_cus > 0 and self.hi > self.lo
+                 and self.native_mstep == "resident" and self._dag_wgs > 0)
+        if split:
+            ncu = self.be.compute_units()
+            _lib.call("magma_set_option", b"resident_max_workgroups", max(1, ncu - self.reserve_cus))
+        elif aside:
+            _lib.call("magma_set_option", b"resident_max_workgroups", 0)
+        fut0 = self.be.run_aside(run0) if aside else None
         if fut0 is None:
             r0 = run0()
 
@@ -652,8 +667,6 @@ class Engine:
                 return self.be.indiv_eval(x, True, active=act)
             if self.hi > self.lo:
                 if hasattr(self.be, "indiv_mstep_resident") and self.native_mstep == "resident":
-                    cap = self.resident_wg_cap if fut0 is not None else 0
-                    _lib.call("magma_set_option", b"resident_max_workgroups", cap)
                     ri = self.be.indiv_mstep_resident(theta_i[self.lo:self.hi], **kw)
                     self.stats["indiv_rounds"] += ri["rounds"]
                 elif hasattr(self.be, "indiv_mstep") and self.native_mstep:
@@ -669,6 +682,8 @@ class Engine:
             new_theta_i = self.comm.allgather_rows(loc, self.counts, like=like)
         if fut0 is not None:
             r0 = fut0()
+        if split:
+            _lib.call("magma_set_option", b"resident_max_workgroups", 0)
         new_theta0 = self.comm.bcast_host(r0["x"][0], like=like)
         return new_theta0, new_theta_i
 
@@ -678,7 +693,14 @@ class Engine:
         E-step, M-step, the two logL_monitoring calls. Returns (new_theta0, new_theta_i,
         logLL at hp, logLL at new hp)."""
         pen_e = float(np.mean(theta_i[:, 2]))  # CF:381 (signed mean)
-        self.e_step(theta0, theta_i, pen_e, m0)
+        info = self.e_step(theta0, theta_i, pen_e, m0)
+        if info != 0:
+            # K_0 or the hyper-posterior precision is not positive definite (or the one-launch
+            # inverse gave up, -999): mean / cov are garbage and nothing may be optimised on them
+            # (the reference would go through MASS::ginv here, CF:133,387)
+            raise np.linalg.LinAlgError(
+                f"E-step: {'K_0' if info > 0 else 'hyper-posterior precision'} not positive "
+                f"definite (info={info})")
         new_theta0, new_theta_i = self.m_step(theta0, theta_i, common_hp, opt_kw)
         if np.any(np.isnan(new_theta0)) or np.any(np.isnan(new_theta_i)):
             return new_theta0, new_theta_i, np.nan, np.nan

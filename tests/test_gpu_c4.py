@@ -1,0 +1,149 @@
+"""BASELINE.json config 4 end to end at full size: M = 2,000 individuals x 50 points on a union
+grid of N = 8,000 ("dense FP64 MFMA Cholesky/TRSM dominated, hyper-posterior + predict").
+
+The oracle's N x N LU inverses take minutes at this size, so the dense parts are checked through
+size-independent properties against independent FP64 arithmetic (torch matrix products on the
+GPU, used here as a CHECKER only), and the prediction against the oracle's
+pred_gp on the blocks of the hyper-posterior it needs (MAGMA.R:135-181):
+  * (K_0^-1 + sum_i scatter K_i^-1) cov = I and cov exactly symmetric (CF:382-387);
+  * mean solves (K_0^-1 + sum ...) mean = K_0^-1 m_0 + w (CF:390-391);
+  * theta_0 objective: f-only == f of the f+g call, gradient vs central differences
+    (CF:181-201, 304-332 at length(hp) == 2) -- the N = 8,000 gemm_nt / gemm_nt_lower path;
+  * the consumers read only what the E-step wrote: the same E-step on a P whose strict upper
+    triangle was poisoned beforehand gives the identical covariance;
+  * pred_gp_batched against orc.pred_gp for new individuals (KAT-3's shape: 20 observations,
+    10 targets), and per-individual objectives against the oracle on cov blocks.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import magma_oracle as orc  # noqa: E402  (checker only)
+
+M, n, N = 2000, 50, 8000
+
+
+@pytest.fixture(scope="module")
+def c4():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
+    import magma_amd as m
+    from magma_amd.synth import simu_db
+    db, a = simu_db(M, n, N, seed=1004)
+    rng = np.random.default_rng(4)
+    ids = orc.unique_in_order(db["ID"])
+    thi = np.column_stack([rng.uniform(0, 3, M), rng.uniform(0, 2, M), rng.uniform(0.3, 2, M)])
+    hp = {"theta_0": np.array([1.5, 0.8]), "theta_i": {i: thi[k] for k, i in enumerate(ids)}}
+    grid = a["grid"]
+    new_dbs, tss = [], []
+    for b, nb in enumerate([20, 1, 33, 64, 7]):
+        t = np.sort(rng.choice(grid, nb + 10, replace=False))
+        new_dbs.append({"Timestamp": t[:nb], "Output": 0.5 * t[:nb] + rng.normal(size=nb)})
+        tss.append(t[nb:])
+    pen, m0 = 0.9, 0.3
+    eng = m.posterior_mu_resident(db, new_dbs, grid, m0, m.kernel_mu, m.kernel, hp, pen_diag=pen)
+    assert eng.ds.N == N and eng.be.Np == 8000
+    return dict(torch=torch, m=m, db=db, a=a, hp=hp, thi=thi, eng=eng, new_dbs=new_dbs, tss=tss,
+                pen=pen, m0=m0, grid=grid)
+
+
+def test_c4_hyperposterior_inverts_the_precision(c4):
+    torch, eng, be = c4["torch"], c4["eng"], c4["eng"].be
+    Np = be.Np
+    cov = be.P.view(Np, Np).clone()      # column-major == row-major: symmetric
+    mean = be.mean.clone()
+    assert torch.equal(cov, cov.t())
+    try:
+        # the sum S = sum_i scatter(K_i^-1) again (lower triangle), and K_0 itself:
+        # (K_0^-1 + S) cov = I  <=>  cov + K_0 (S cov) = K_0, checked with torch products only
+        P, w = be.estep_scatter(c4["thi"])
+        Pl = torch.tril(P.view(Np, Np).t().clone())
+        S = Pl + torch.tril(Pl, -1).t()
+        w = w.clone()
+        from magma_amd import _lib
+        K0 = torch.empty(Np * Np, dtype=torch.float64, device="cuda")
+        _lib.call("magma_kern_to_cov_grid", N, C.c_void_p(be.grid.data_ptr()), 1.5, 0.8, c4["pen"],
+                  C.c_void_p(K0.data_ptr()), be.stream())
+        K0 = K0.view(Np, Np)
+        resid = (cov + K0 @ (S @ cov) - K0).abs().max().item()
+        assert resid < 1e-9 * K0.abs().max().item(), resid
+        m0v = torch.full((Np,), c4["m0"], dtype=torch.float64, device="cuda")
+        rhs = m0v + K0 @ w
+        err = (mean + K0 @ (S @ mean) - rhs).abs().max().item()
+        assert err < 1e-9 * rhs.abs().max().item(), err
+    finally:
+        # restore the hyper-posterior for the tests below -- with the strict upper triangle of
+        # the buffer poisoned before the dense part of the E-step: nothing may read it
+        be.set_m0(c4["m0"])
+        P2, _ = be.estep_scatter(c4["thi"])
+        up = torch.triu(torch.ones(Np, Np, dtype=torch.bool, device="cuda"), 1)
+        P2.view(Np, Np).t()[up] = float("nan")   # element (r, c), c > r, of the column-major P
+        del up
+        be._a0_key = None
+        info, f0 = be.estep_finish(c4["hp"]["theta_0"], c4["pen"], want_f0=True)
+    assert info == 0 and np.isfinite(f0)
+    assert torch.equal(be.P.view(Np, Np), cov) and torch.equal(be.mean, mean)
+
+
+def test_c4_theta0_objective_and_gradient(c4):
+    be = c4["eng"].be
+    t0 = np.array([1.3, 0.7])
+    f, g, info = be.theta0_eval(t0, 0.5, True)
+    f2, _, _ = be.theta0_eval(t0, 0.5, False)
+    assert info == 0 and abs(f - f2) < 1e-12 * abs(f)
+    h = 1e-5
+    for k in range(2):
+        e = np.zeros(2)
+        e[k] = h
+        fd = (be.theta0_eval(t0 + e, 0.5, False)[0] - be.theta0_eval(t0 - e, 0.5, False)[0]) / (2 * h)
+        assert abs(fd - g[k]) < 2e-5 * max(1.0, abs(g[k])), (k, fd, g[k])
+    # the native optimiser loop around it decreases the objective (CF:412-413)
+    r = be.theta0_mstep(np.array([1.0, 1.0]), 0.5, maxit=3)
+    assert r["f"][0] < r["f_x0"][0] and r["status"][0] in (1, 3)
+
+
+def test_c4_per_individual_objectives_and_prediction_match_oracle(c4):
+    m, eng, be = c4["m"], c4["eng"], c4["eng"].be
+    cov = be.get_cov()            # 512 MB on the host: the oracle's input
+    mean = be.get_mean()
+    labels = eng.ds.grid
+    mean_db = {"Timestamp": labels, "Output": mean}
+    # M-step objective + gradient of a sample of individuals (gather of C_i from the 8000^2 cov)
+    th = c4["thi"] + 0.1
+    f, g = be.indiv_eval(th, True)
+    for k in (0, 1, 777, M - 1):
+        s = slice(eng.ds.off[k], eng.ds.off[k + 1])
+        db_k = {"Timestamp": eng.ds.t[s], "Output": eng.ds.y[s]}
+        c_k = orc._block(labels, cov, db_k["Timestamp"])
+        m_k = orc._mean_at(mean_db, db_k["Timestamp"])
+        f_o = orc.logL_GP_mod(th[k], db_k, m_k, orc.kernel, c_k)
+        g_o = orc.gr_GP_mod(th[k], db_k, m_k, orc.kernel, c_k)
+        assert abs(f[k] - f_o) < 1e-10 * max(1.0, abs(f_o)), (k, f[k], f_o)
+        assert np.abs(g[k] - g_o).max() < 1e-8 * max(1.0, np.abs(g_o).max()), (k, g[k], g_o)
+    # prediction for new individuals against the resident hyper-posterior
+    B = len(c4["new_dbs"])
+    rng = np.random.default_rng(8)
+    thetas = np.column_stack([rng.uniform(0, 2, B), rng.uniform(0, 1, B)])
+    sigmas = rng.uniform(0.2, 1.0, B)
+    got = m.pred_gp_batched(eng, c4["new_dbs"], c4["tss"], thetas, sigmas)
+    for b, nd in enumerate(c4["new_dbs"]):
+        exp = orc.pred_gp(nd, c4["tss"][b], mean_db, (labels, cov), orc.kernel, thetas[b], sigmas[b])
+        assert np.abs(got[b]["Mean"] - exp["Mean"]).max() < 1e-8 * max(1.0, np.abs(exp["Mean"]).max()), b
+        assert np.abs(got[b]["Var"] - exp["Var"]).max() < 1e-8 * max(1.0, np.abs(exp["Var"]).max()), b
+
+
+def test_c4_em_iteration_runs_and_increases_the_likelihood(c4):
+    """One full EM iteration at C4 size through the default routes (resident M-step, theta_0 chain
+    on the side stream): finite, and logL(new hp) >= logL(hp) as EM guarantees (MG:54-64)."""
+    from magma_amd.engine import Dataset, Engine
+    a = c4["a"]
+    ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    eng = Engine(ds)
+    th0 = np.array([1.0, 1.0])
+    thi = np.tile([1.0, 1.0, 0.2], (M, 1))
+    n0, ni, l_old, l_new = eng.em_iteration(th0, thi, 0.0, False, {"maxit": 5})
+    assert np.all(np.isfinite(n0)) and np.all(np.isfinite(ni))
+    assert np.isfinite(l_old) and l_new > l_old

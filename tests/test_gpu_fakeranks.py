@@ -1,0 +1,160 @@
+"""One GPU pretending to be k ranks: k `Engine`s over contiguous shards
+of BASELINE config 5 (M = 100,000 individuals x 40 points, union grid N = 2,000) run side by side
+on cuda:0, one host thread each, with an in-process communicator that sums their partial
+precision / weighted-mean / objective pieces exactly where torch.distributed would. The sharded
+run must equal the 1-rank engine up to summation order -- for the E-step and for one full EM
+iteration (E + M + both monitorings, CF:371-437, MG:32-75). This exercises the N > 1 code path of
+`Engine` (shard bounds, all-reduce of P and w, 4-double sums, theta_i all-gather, theta_0
+broadcast) on real device buffers, which the gloo tests on CPU cannot."""
+import threading
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadComm:
+    """Same interface as magma_amd.engine.Comm for `world` ranks that are threads of one process.
+    Every collective is: deposit, barrier, combine in rank order (so all ranks compute the same
+    bits), barrier."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, item):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        self.sh.slots[self.rank] = item
+        self.sh.barrier.wait()
+        items = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return items
+
+    def allreduce_(self, tensor):
+        items = self._exchange(tensor.clone())
+        tensor.zero_()
+        for it in items:
+            tensor.add_(it)
+        return tensor
+
+    def allreduce_host(self, arr, like=None):
+        items = self._exchange(np.array(arr, dtype=np.float64))
+        return np.sum(items, axis=0)
+
+    def bcast_host(self, arr, like=None, src=0):
+        return self._exchange(np.array(arr, dtype=np.float64))[src]
+
+    def allgather_rows(self, local, counts, like=None):
+        return np.concatenate(self._exchange(np.array(local, dtype=np.float64)), axis=0)
+
+
+def _run_ranks(ds, world, fn):
+    """fn(engine) on `world` engines over the shards of ds, one thread per rank; returns the
+    per-rank results (exceptions re-raised)."""
+    import torch
+    from magma_amd.engine import Engine
+    shared = ThreadComm.Shared(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            eng = Engine(ds, comm=ThreadComm(shared, r))
+            out[r] = fn(eng)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared.barrier.abort()
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+TH0 = np.array([1.0, 1.0])
+
+
+def _thi(M):
+    return np.tile([1.0, 1.0, 0.2], (M, 1))
+
+
+def _one_iteration(eng, inject=None):
+    """E-step, then one whole EM iteration (E + M + monitoring) at the reference's optimiser
+    settings; with `inject` = (mean, cov) of the 1-rank run also the M-step alone on EXACTLY that
+    hyper-posterior, where every per-individual problem has bit-identical inputs."""
+    M = eng.ds.M
+    info = eng.e_step(TH0, _thi(M), 0.2, 0.3)
+    out = dict(info=info, cov_diag=eng.be.get_cov_diag(), mean=eng.be.get_mean(), f0=eng.last_f0,
+               lo=eng.lo, hi=eng.hi, cov=eng.be.get_cov() if eng.lo == 0 else None)
+    n0, ni, l_old, l_new = eng.em_iteration(TH0, _thi(M), 0.3, False)
+    out.update(n0=n0, ni=ni, l_old=l_old, l_new=l_new)
+    if inject is not None:
+        eng.be.set_mean_cov(*inject)
+        eng.be.set_m0(0.3)
+        m0, mi = eng.m_step(TH0, _thi(M), False)
+        out.update(m0=m0, mi=mi, sum_fi=eng.last_sum_fi, sum_fi_new=eng.last_sum_fi_new)
+    return out
+
+
+@pytest.fixture(scope="module")
+def c5():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
+    from magma_amd.engine import Dataset, Engine
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(100000, 40, 2000, seed=1005)
+    ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    eng = Engine(ds)
+    eng.e_step(TH0, _thi(ds.M), 0.2, 0.3)
+    post = (eng.be.get_mean(), eng.be.get_cov())
+    ref = _one_iteration(eng, inject=post)
+    del eng
+    torch.cuda.empty_cache()
+    return ds, ref, post
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_c5_sharded_em_iteration_equals_one_rank(c5, world):
+    ds, ref, post = c5
+    res = _run_ranks(ds, world, lambda eng: _one_iteration(eng, inject=post))
+    assert [r["lo"] for r in res] == [k * (ds.M // world) for k in range(world)]
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())  # noqa: E731
+    for r in res:
+        assert r["info"] == 0
+        # E-step: the all-reduced precision / weighted mean differ by summation order only
+        assert rel(r["mean"], ref["mean"]) < 1e-12 and rel(r["cov_diag"], ref["cov_diag"]) < 1e-12
+        assert rel(r["f0"], ref["f0"]) < 1e-12
+        # every rank ends with the same replicated hyper-parameters and log-likelihoods, bit for bit
+        for k in ("n0", "ni", "m0", "mi"):
+            assert np.array_equal(r[k], res[0][k]), k
+        assert r["l_old"] == res[0]["l_old"] and r["l_new"] == res[0]["l_new"]
+    r0 = res[0]
+    assert rel(r0["cov"], ref["cov"]) < 1e-12
+    assert rel(r0["l_old"], ref["l_old"]) < 1e-12
+    # M-step on the injected (bit-identical) hyper-posterior: each individual's optimisation has
+    # the same inputs whichever rank runs it -> identical theta_i after the all-gather, identical
+    # theta_0; the summed objective pieces differ by summation order only
+    assert np.array_equal(r0["mi"], ref["mi"]) and np.array_equal(r0["m0"], ref["m0"])
+    assert rel(r0["sum_fi"], ref["sum_fi"]) < 1e-13 and rel(r0["sum_fi_new"], ref["sum_fi_new"]) < 1e-13
+    # the whole EM iteration: its M-step starts from hyper-posteriors that differ by ~1e-14, and
+    # 10^5 independent L-BFGS-B runs amplify that: almost all end at the same optimum to the
+    # optimiser's tolerance (factr = 1e7), a few near a line-search decision boundary take another
+    # path (some of these likelihoods have two basins) -- so the summed log-likelihood agrees to
+    # ~1e-6, not to rounding. The bit-identical M-step above is the check of the sharding logic.
+    q = np.abs(r0["ni"] - ref["ni"]).max(axis=1)
+    print(f"world {world}: l_new rel diff {rel(r0['l_new'], ref['l_new']):.2e}; theta_i max-abs "
+          f"diff: median {np.median(q):.2e}, 99% {np.quantile(q, 0.99):.2e}, "
+          f"share > 1e-3: {np.mean(q > 1e-3):.4f}; theta_0 diff {np.abs(r0['n0'] - ref['n0']).max():.2e}")
+    assert rel(r0["l_new"], ref["l_new"]) < 2e-5
+    assert np.abs(r0["n0"] - ref["n0"]).max() < 1e-5
+    assert np.median(q) < 1e-6 and np.mean(q > 1e-3) < 0.02

@@ -39,9 +39,19 @@ def test_reference_results_reproduced_on_gpu(m, name):
     got, exp = run_kat(name, m.posterior_mu, m.pred_gp, m.kernel)
     rel = np.abs(got[:, 0] - exp[:, 0]) / np.abs(exp[:, 0])
     assert np.median(rel) < 1e-11, (name, np.median(rel))
-    for d in np.nonzero(rel >= TOL[name])[0] + 1:
+    loose = np.nonzero(rel >= TOL[name])[0] + 1
+    for d in loose:
         lim = 200 * np.finfo(float).eps * _cond_k0(name, int(d))
         assert rel[d - 1] < lim, (name, int(d), rel[d - 1], lim)
+    # how many datasets needed the cond(K_0)-scaled bound, and the worst error on each side of it
+    # (run with -s / -rP to see it; also kept in the JUnit/"passed" section of the report)
+    tight = rel[rel < TOL[name]]
+    print(f"{name}: {tight.size}/100 datasets within {TOL[name]:g} (worst {tight.max():.2e}); "
+          f"{loose.size} took the 200*eps*cond(K_0) bound"
+          + (f" (datasets {list(map(int, loose))}, worst rel err {rel[loose - 1].max():.2e})"
+             if loose.size else ""))
+    # at most a handful of stored models are that ill-conditioned
+    assert loose.size <= 5, (name, list(map(int, loose)))
     # CI95 coverage is a count: identical unless a point sits within rounding of a band edge
     assert np.abs(got[:, 1] - exp[:, 1]).max() < 1e-9, name
 
