@@ -132,6 +132,15 @@ int magma_dmvnorm(int n, const double* x, const double* mu, double* inv_Sigma, v
 /* Dense SPD inverse + log-det on its own (solve(), determinant(): CF:27,133,387). A: in =
  * SPD matrix (lower triangle read), out = full symmetric inverse. d_logdet, d_info: device. */
 int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* work, void* stream);
+/* magma_spd_inverse for N <= 1024 WITHOUT a caller workspace and without any allocation. No
+ * counterpart in the reference: it exists for callers that cannot allocate device memory -- code
+ * under HIP graph capture, tight serving loops (kern_to_inv / solve() of a prediction grid per
+ * request), harnesses that forbid hipMalloc. The 24 MiB workspace is a static device array of
+ * the library, one copy per GPU, held until the process ends; its device address is looked up
+ * once per device on the first call there. Same kernels and results as magma_spd_inverse. Calls
+ * that overlap on one GPU (two streams, two threads) share that array and race: serialise them.
+ * N > 1024 is rejected (status 2, magma_last_error says why). */
+int magma_spd_inverse_static(int N, double* A, double* d_logdet, int* d_info, void* stream);
 
 /* ---- (4) M-step objective and gradient ---- */
 /* mode 0: logL_GP_mod + gr_GP_mod per individual (CF:181-201, 304-332) with mean = mean[idx],

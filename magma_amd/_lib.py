@@ -40,6 +40,7 @@ SIGNATURES = {
     "magma_estep_finish": (_i, [_i, _p, _d, _d, _d, _p, _p, _p, _p, _p, _i, C.POINTER(_d),
                                 C.POINTER(_i), _p]),
     "magma_spd_inverse": (_i, [_i, _p, _p, _p, _p, _p]),
+    "magma_spd_inverse_static": (_i, [_i, _p, _p, _p, _p]),
     "magma_update_inv": (_i, [_i, _p, _p, _p, _p, _i, _p, _p]),
     "magma_update_mean": (_i, [_i, _p, _p, _p, _p, _p, _i, _p, _p]),
     "magma_dmvnorm": (_i, [_i, _p, _p, _p, _p, C.POINTER(_d), C.POINTER(_i), _p]),

@@ -186,6 +186,43 @@ int magma_spd_inverse(int N, double* A, double* d_logdet, int* d_info, void* wor
   return launch_spd_inverse(Np, A, d_logdet, d_info, wk.inv, S(stream));
 }
 
+// ---- the one entry point that allocates nothing (see the header) ----
+// Workspace of the dense inverse for N <= MAGMA_STATIC_NMAX, held by every GPU the library runs on
+// until the process ends: 3 Np^2 doubles at Np = 1024 = 24 MiB.
+#define MAGMA_STATIC_NMAX 1024
+static __device__ __align__(256) double scratch[3 * (size_t)MAGMA_STATIC_NMAX * MAGMA_STATIC_NMAX];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device: each GPU holds its own copy
+}  // namespace
+
+int magma_spd_inverse_static(int N, double* A, double* d_logdet, int* d_info, void* stream) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  if (N > MAGMA_STATIC_NMAX)
+    return fail(2, "magma_spd_inverse_static: N exceeds 1024, the size its built-in workspace is "
+                   "made for (use magma_spd_inverse with a caller workspace)");
+  int dev = 0;
+  MAGMA_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(2, "magma_spd_inverse_static: device index out of range");
+  double* ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+      // set-up, once per device, with that device current: the array's name is a host-side
+      // stand-in, its device address comes from the runtime
+      void* p = nullptr;
+      MAGMA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      if (p == nullptr) return fail(3, "magma_spd_inverse_static: no device address for the workspace");
+      g_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    ws = g_scratch_ptr[dev];
+  }
+  // same kernels as magma_spd_inverse; they clear what must start at zero (flags, ticket
+  // counter, log-det, info: hipMemsetAsync on the stream) and write L, U before reading them
+  return launch_spd_inverse(magma_pad(N), A, d_logdet, d_info, ws, S(stream));
+}
+
 int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
                        const double* m0, double* P, double* w, double* mean_out, void* work,
                        int reuse_k0inv, double* h_f0, int* h_info, void* stream) {
