@@ -8,10 +8,17 @@ the EM trajectory from the reference's initial hyper-parameters on synthetic dat
 reference's simulation recipe. Default workload = BASELINE.json configs[2] ("c3"): M = 10,000
 individuals x 50 points per GPU, union grid N = 2,000, individual hyper-parameters.
 
-With N GPUs (launched by torch.distributed.run, one rank per GPU, RCCL) every rank holds
-10,000 individuals (weak scaling); `value` is the whole-job rate in units of "EM iterations of
-a 10k-task problem per second" = steps * (M_total / 10,000) / seconds, so that N = 1 is exactly
-BASELINE.json's metric.
+The K timed iterations start again from the reference's initial hyper-parameters after the W
+warmup iterations (--trajectory restart, the default), so the expensive first iterations of a
+fit are inside the timed region; `fit` reports the iterations up to the reference's stopping rule
+(eps < 1e-3) on their own, `steady_state` the cheap tail; --fit times one training() call.
+
+With N GPUs (launched by torch.distributed.run, one rank per GPU; the EM's collectives run on the
+library's own RCCL communicator) every rank holds 10,000 individuals (--scaling weak, default), or
+the N ranks share the configuration's M (--scaling strong: c3 = the north star's M = 10^4 fit,
+c5 = BASELINE's M = 10^5); `value` is the whole-job rate in units of "EM iterations of a 10k-task
+problem per second" = steps * (M_total / 10,000) / seconds, so that N = 1 is exactly BASELINE.json's
+metric.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
 timed region) and `cpu_baseline` (the CPU oracle = NumPy/LAPACK restatement of the R code,
@@ -44,33 +51,28 @@ PROF_NAMES = ["gemm_nt(T=Kinv*C)", "theta0_contract", "spd_inverse", "indiv_eval
               "indiv_gather_cov", "indiv_mstep(resident)"]
 
 
-def pmc_traffic(kernel_class, evals_per_launch):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_fetch_write.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of
-    this script; counters are in KB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    wide coalesced loads on gfx950). Counters cannot be read inside a timed run, so the per
-    workgroup (= per evaluated individual) figure is scaled to this run's launch size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        "r01_pmc_fetch_write.json")
-    keys = {"indiv_eval(f+grad)": "magma::indiv_eval_kernel<52>",
-            "indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>",
+def pmc_traffic(kernel_class, args):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    THIS command line (profiles/r02_pmc_<config>_<steps>_<warmup>.json, made by
+    profiles/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate runs; counters in
+    KB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced loads on gfx950).
+    Counters cannot be read inside a timed run; a file made with other --steps / --warmup /
+    --config is not used: then the figure is null."""
+    name = f"r02_pmc_{args.config}_{args.steps}_{args.warmup}.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    keys = {"indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>",
             "spd_inverse": "magma::spd_inverse_dag_kernel",
             "gemm_nt(T=Kinv*C)": "magma::gemm_nt_kernel"}
     if kernel_class not in keys or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as fh:
         pmc = json.load(fh)
     key = keys[kernel_class]
     try:
-        if kernel_class in ("indiv_mstep(resident)", "spd_inverse", "gemm_nt(T=Kinv*C)"):
-            # one fixed-size launch per call: the profiled runs' average is this run's figure
-            kb = 2.0 * pmc["FETCH_SIZE"][key]["avg_kb"] + pmc["WRITE_SIZE"][key]["avg_kb"]
-            return kb * 1024.0
-        kb = 2.0 * pmc["FETCH_SIZE"][key]["kb_per_workgroup_at_max"] \
-            + pmc["WRITE_SIZE"][key]["kb_per_workgroup_at_max"]
+        kb = 2.0 * pmc["FETCH_SIZE"][key]["avg_kb"] + pmc["WRITE_SIZE"][key]["avg_kb"]
     except KeyError:
-        return None
-    return kb * 1024.0 * evals_per_launch
+        return None, None
+    return kb * 1024.0, "profiles/" + name
 
 
 def cpu_baseline(cfg):
@@ -126,6 +128,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N GPUs: weak = the config's M per GPU; strong = the config's M in total "
+                         "(c3: the north star's M = 10^4 fit; c5: M = 10^5), sharded over the ranks")
+    ap.add_argument("--trajectory", default="restart", choices=["restart", "continue"],
+                    help="restart (default): the K timed EM iterations start again from the "
+                         "reference's initial hyper-parameters after the warmup iterations (so the "
+                         "expensive first iterations of a fit are inside the timed region); "
+                         "continue: they go on where the warmup stopped (steady state)")
+    ap.add_argument("--fit", action="store_true",
+                    help="time ONE call of training() (MAGMA.R:15-82) to the reference's stopping "
+                         "rule instead of K iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,19 +153,30 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from magma_amd import _lib
-    from magma_amd.engine import Dataset, Engine, Comm
+    from magma_amd.engine import Dataset
+    from magma_amd.native import NativeEngine, unique_id
     from magma_amd.synth import simu_arrays
     lib = _lib.load()
 
     cfg = dict(CONFIGS[args.config])
-    M_total = cfg["M"] * world
+    if args.config == "c5" and args.scaling == "strong":
+        cfg["M"] = 100000  # BASELINE config 5: M = 100,000 in total, sharded 1/2/4/8 ways
+    M_total = cfg["M"] * (world if args.scaling == "weak" else 1)
     a = simu_arrays(M_total, cfg["n"], cfg["N"], cfg["common_times"], cfg["common_hp"],
                     seed=cfg["seed"])
     ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
-    eng = Engine(ds, comm=Comm(dist), device=torch.device("cuda", local))
-    theta0 = np.array([1.0, 1.0])
-    theta_i = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+    uid = None
+    if world > 1:
+        # the library's own RCCL communicator: rank 0's unique id, handed round by the launcher's
+        # process group; every collective of the EM then runs inside libmagma_hip.so
+        box = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            box.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
+        dist.broadcast(box, 0)
+        uid = bytes(box.cpu().numpy().tobytes())
+    eng = NativeEngine(ds, rank=rank, world=world, unique_id=uid, device=torch.device("cuda", local))
     common = cfg["common_hp"]
+    ini0, ini_i = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (ds.M, 1))
 
     def barrier():
         if dist is not None:
@@ -165,19 +189,32 @@ def main():
             raise RuntimeError("EM iteration produced NaN hyper-parameters")
         return n0, ni, l_old, l_new
 
+    theta0, theta_i = ini0.copy(), ini_i.copy()
     for _ in range(args.warmup):
         theta0, theta_i, _, _ = step(theta0, theta_i)
-    for k in eng.stats:
-        eng.stats[k] = 0
-    eng.be.n_evals = 0
+    if args.trajectory == "restart":
+        theta0, theta_i = ini0.copy(), ini_i.copy()
+    eng.reset_stats()
     lib.magma_prof_reset()
     lib.magma_prof_enable(1)
+    lls, epss, step_ms = [], [], []
+    fit = None
     barrier()
     t0 = time.perf_counter()
-    lls = []
-    for _ in range(args.steps):
-        theta0, theta_i, l_old, l_new = step(theta0, theta_i)
-        lls.append(l_old)
+    if args.fit:
+        trace = []
+        theta0, theta_i, cv = eng.training(0.0, ini0, ini_i[0], common, trace=trace)
+        lls = [r["logLL"] for r in trace]
+        epss = [r["eps"] for r in trace]
+        n_steps = len(trace)
+    else:
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            theta0, theta_i, l_old, l_new = step(theta0, theta_i)
+            step_ms.append(1e3 * (time.perf_counter() - t1))
+            lls.append(l_old)
+            epss.append((l_new - l_old) / abs(l_new))
+        n_steps = args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     lib.magma_prof_enable(0)
@@ -186,8 +223,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stats = dict(eng.stats)
-    n_evals = eng.be.n_evals
+    stats = eng.stats
+    n_evals = stats["indiv_evals"]
+    prof = {}
+    for pid, name in enumerate(PROF_NAMES):
+        cnt, ms = C.c_int(0), C.c_double(0.0)
+        lib.magma_prof_get(pid, C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            prof[name] = {"launches": cnt.value, "total_ms": ms.value, "avg_ms": ms.value / cnt.value}
+
     # the three rates behind an "EM iteration" (whose evaluation counts are data
     # dependent), each timed alone after the timed region on the final hyper-parameters
     def rate(fn, reps=3):
@@ -200,44 +244,28 @@ def main():
         return reps / (time.perf_counter() - t1)
     pen_e = float(np.mean(theta_i[:, 2]))
     rates = {"e_step_per_s": rate(lambda: eng.e_step(theta0, theta_i, pen_e, 0.0)),
-             "theta0_f_and_grad_evals_per_s": rate(lambda: eng.f0(theta0, 2.0 * pen_e, True))}
-    if not common:
-        rates["indiv_sweeps_per_s"] = rate(
-            lambda: eng.be.indiv_eval(theta_i[eng.lo:eng.hi], True))
-
-    prof = {}
-    for pid, name in enumerate(PROF_NAMES):
-        cnt, ms = C.c_int(0), C.c_double(0.0)
-        lib.magma_prof_get(pid, C.byref(cnt), C.byref(ms))
-        if cnt.value:
-            prof[name] = {"launches": cnt.value, "total_ms": ms.value, "avg_ms": ms.value / cnt.value}
+             "logL_monitoring_per_s": rate(lambda: eng.logL_monitoring(theta0, theta_i))}
 
     if rank == 0:
-        N, n, Mloc = cfg["N"], cfg["n"], cfg["M"]
-        value = args.steps * (M_total / 10000.0 if args.config == "c3" else 1.0) / elapsed
-        S3 = Mloc * n ** 3
+        N, n, Mloc = cfg["N"], cfg["n"], eng.hi - eng.lo
+        units = M_total / 10000.0 if args.config == "c3" else 1.0
+        value = n_steps * units / elapsed
         S2 = Mloc * n ** 2
-        ng = max(1, prof.get("indiv_eval(f+grad)", {}).get("launches", 0)
-                 or prof.get("indiv_mstep(resident)", {}).get("launches", 1))
+        nres = max(1, prof.get("indiv_mstep(resident)", {}).get("launches", 1))
         # algorithmic work per launch; FP64 FMA peak = FP64 MFMA peak on
         # MI355X, so the per-individual FP64 kernels are priced against the same 78.6 TFLOP/s
         alg = {
-            "gemm_nt(T=Kinv*C)": ("mfma", 2.0 * N ** 3, True),
+            # (with several ranks each forms its share of the block rows: priced on what runs)
+            "gemm_nt(T=Kinv*C)": ("mfma", 2.0 * N ** 3 / world, True),
             # Z = T K^-1 is symmetric: only its lower tiles are formed (N^3 executed of the 2 N^3
             # a full product would take); priced on what runs
-            "theta0_contract": ("mfma", 1.0 * N ** 3, True),
+            "theta0_contract": ("mfma", 1.0 * N ** 3 / world, False),
             # one launch (the tile graph) up to 64 block rows; above that ~75 launches per call
-            "spd_inverse": ("mfma", 1.0 * N ** 3, (N + 63) // 64 <= 64
-                            and os.environ.get("MAGMA_DAG_WGS", "256") != "0"),
-            # 5 n^3 flops x the individuals actually evaluated per launch (active list)
-            "indiv_eval(f+grad)": ("mfma", 5.0 * n ** 3 * n_evals / ng, True),
-            # device-resident M-step: the same 5 n^3 per evaluation, all evaluations of a launch
-            "indiv_mstep(resident)": ("mfma", 5.0 * n ** 3 * n_evals / max(1, prof.get(
-                "indiv_mstep(resident)", {}).get("launches", 1)), True),
-            "indiv_eval(f)": ("mfma", 1.0 * S3, True),
+            "spd_inverse": ("mfma", 1.0 * N ** 3, (N + 63) // 64 <= 64),
+            # device-resident M-step: 5 n^3 per evaluation, all evaluations of a launch
+            "indiv_mstep(resident)": ("mfma", 5.0 * n ** 3 * n_evals / nres, True),
             # E-step sums (three launches with the default deterministic route)
-            "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n,
-                              os.environ.get("MAGMA_SCATTER", "gather") == "atomic"),
+            "estep_scatter": ("hbm", 8.0 * S2 + 20.0 * Mloc * n, False),
         }
         for name, (bound, work, single) in alg.items():
             if name in prof:
@@ -253,26 +281,50 @@ def main():
         dom = max(singles, key=lambda k: prof[k]["total_ms"]) if singles else None
         roof = None
         if dom is not None:
+            traffic, src = pmc_traffic(dom, args)
             roof = {"kernel": dom, "bound": prof[dom]["bound"], "achieved": prof[dom]["achieved"],
                     "peak": prof[dom]["peak"], "unit": prof[dom]["unit"], "frac": prof[dom]["frac"],
-                    "traffic": pmc_traffic(dom, n_evals / ng), "traffic_unit": "bytes/launch",
-                    "avg_launch_ms": prof[dom]["avg_ms"],
-                    "launches": prof[dom]["launches"],
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": src,
+                    "avg_launch_ms": prof[dom]["avg_ms"], "launches": prof[dom]["launches"],
                     "share_of_step_time": prof[dom]["share_of_step_time"]}
-        e0 = stats["theta0_evals"] / args.steps
-        ei = (stats["common_evals"] if common else stats["indiv_rounds"]) / args.steps
+            if dom == "indiv_mstep(resident)":
+                roof["n_evals_per_launch"] = n_evals / nres
+        e0 = stats["theta0_evals"] / n_steps
+        ei = (stats["common_evals"] if common else stats["indiv_rounds"]) / n_steps
+        # the fit inside the timed trajectory: iterations up to the reference's stopping rule
+        # (eps < 1e-3, MAGMA.R:64-71), when the trajectory starts at the initial hyper-parameters
+        if args.fit:
+            fit = {"iterations": n_steps, "wall_ms": 1e3 * elapsed, "it_per_s": n_steps * units / elapsed,
+                   "converged": bool(cv)}
+        elif args.trajectory == "restart":
+            stop = next((k for k, e in enumerate(epss) if e < 1e-3), None)
+            if stop is not None:
+                w = float(np.sum(step_ms[:stop + 1]))
+                fit = {"iterations": stop + 1, "wall_ms": w, "it_per_s": (stop + 1) * units / (w * 1e-3),
+                       "note": "EM iterations 1..k of the timed trajectory, k = first with eps < 1e-3"}
+        steady = None
+        if len(step_ms) >= 8:
+            tail = step_ms[-5:]
+            steady = {"ms_per_step": float(np.mean(tail)), "it_per_s": units / (np.mean(tail) * 1e-3),
+                      "note": "last 5 timed iterations (past the stopping rule: cheaper M-steps)"}
         out = {
             "metric": "EM iterations/sec (E+M) at M=10k tasks", "value": value,
-            "unit": "EM it/s (10k-task units)", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "unit": "EM it/s (10k-task units)", "n_gpus": world, "steps": n_steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / n_steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (simu_scheme recipe, NumPy default_rng)",
             "config": {"workload": f"{args.config}: M={M_total} individuals x {n} points, union grid "
-                                   f"N={N}, {'common' if common else 'individual'} hyper-parameters",
+                                   f"N={N}, {'common' if common else 'individual'} hyper-parameters; "
+                                   + ("one training() call to the stopping rule" if args.fit else
+                                      f"{n_steps} EM iterations "
+                                      + ("from the initial hyper-parameters" if args.trajectory == "restart"
+                                         else "continuing after the warmup iterations")),
                        "M_per_gpu": Mloc, "theta0_evals_per_step": e0,
-                       "indiv_eval_rounds_per_step": ei, "parallelism": f"dp{world}",
-                       "logLL_trace": lls},
-            "roofline": roof, "rates": rates, "kernel_classes": prof,
+                       "indiv_eval_rounds_per_step": ei, "indiv_evals_per_step": n_evals / n_steps,
+                       "parallelism": f"dp{world}", "driver": "native (magma_em_iteration / magma_training)",
+                       "logLL_trace": lls, "eps_trace": epss, "step_ms": step_ms},
+            "roofline": roof, "fit": fit, "steady_state": steady, "rates": rates,
+            "kernel_classes": prof,
         }
         if not args.no_cpu_baseline and world == 1:
             t0c = time.time()
@@ -282,14 +334,14 @@ def main():
             # (each ~ one theta_0 f-evaluation + one f-sweep; priced at half an f+g evaluation)
             t_iter = (cb["t_estep_dense"] + cb["t_estep_per_indiv"] * Mloc
                       + (e0 + 1.0) * cb["t_theta0_eval"]
-                      + cb["t_indiv_eval"] * (n_evals / args.steps + Mloc))
+                      + cb["t_indiv_eval"] * (n_evals / n_steps + Mloc))
             try:
                 import threadpoolctl
                 cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) or 1
             except Exception:
                 cores = os.cpu_count()
             out["cpu_baseline"] = {
-                "value": (Mloc / 10000.0 if args.config == "c3" else 1.0) / t_iter,
+                "value": units / t_iter,
                 "unit": "EM it/s (10k-task units)", "cores": cores, "kind": "port",
                 "sample": f"CPU restatement of the reference (R not present): dense parts at "
                           f"full N={N}; per-individual parts timed on "
@@ -297,6 +349,7 @@ def main():
                           f"evaluation counts of the GPU run; {time.time() - t0c:.1f}s of CPU work",
                 "pieces_s": {k: v for k, v in cb.items() if k != "Ms"}}
         print(json.dumps(out))
+    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -216,6 +216,119 @@ int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double
 /* Sum of n doubles (deterministic order) -> h_out on the host. Synchronises. */
 int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* stream);
 
+/* ---- context / dataset / driver: ONE native call per reference function ----
+ * The EM driver of the reference lives in R (`training`, MG:15-82, calling `e_step`, `m_step`,
+ * `logL_monitoring`, CF:371-437, 236-264). These entry points run it inside the library, so a
+ * host language binds `magma_training` (or one call per reference function) instead of a call per
+ * kernel; the device-resident data, streams, the theta_0 side stream and the communicator stay
+ * behind two opaque handles.
+ *  - magma_ctx: one GPU of one rank: device, a main and a high-priority side stream, and the
+ *    communicator of a multi-GPU job (one context per GPU; one host thread uses a context at a
+ *    time). world == 1 needs no communicator. For world > 1 either RCCL (magma_comm_unique_id on
+ *    one rank, the 128 bytes passed to every rank by the host's own means, then
+ *    magma_ctx_create_rccl on each rank with its device current: ncclCommInitRank inside;
+ *    librccl is opened with dlopen, not linked) or a caller-supplied all-reduce callback (sum over
+ *    ranks, in place, of `count` doubles in DEVICE memory; called with the data complete, may
+ *    block; return 0 = ok) -- used by the tests to run several ranks as threads on one GPU.
+ *  - magma_dataset: this rank's shard of a db (individuals row0 .. row0 + M - 1 of M_total) on a
+ *    union grid of N points, uploaded once, with every buffer the EM needs (precision / cov,
+ *    dense workspace, the gather lists of the deterministic E-step, packed cov blocks, optimiser
+ *    outputs). Host arrays in: ragged off[M + 1] (off[0] = 0), t, y (timestamps strictly ascending
+ *    within an individual, every one of them present in grid; n_i <= 64), grid ascending.
+ * Hyper-parameters are HOST arrays: theta_0 = 2 doubles; theta_i = (theta1, theta2, sigma) rows of
+ * ALL M_total individuals (replicated on every rank; pen_diag averages over all of them, CF:381,
+ * 409), or one triple with theta_stride 0. Calls are blocking; results in host memory. */
+typedef struct magma_ctx magma_ctx;
+typedef struct magma_dataset magma_dataset;
+typedef int (*magma_allreduce_fn)(void* user, double* dev_buf, int64_t count, void* stream);
+typedef struct {
+  int64_t theta0_evals; /* dense theta_0 evaluations (M-step + monitoring) */
+  int64_t indiv_rounds; /* longest per-individual evaluation chain, summed over M-steps */
+  int64_t indiv_evals;  /* per-individual objective + gradient evaluations on this rank */
+  int64_t common_evals; /* evaluations of the common-HP objective */
+  int64_t flagged;      /* individuals whose K_i was not positive definite in an E-step */
+} magma_em_stats;
+
+int magma_comm_unique_id(void* h_out128);
+int magma_ctx_create(magma_ctx** out, int device);
+int magma_ctx_create_rccl(magma_ctx** out, int device, int rank, int world, const void* h_unique_id128);
+int magma_ctx_create_callback(magma_ctx** out, int device, int rank, int world,
+                              magma_allreduce_fn fn, void* user);
+void magma_ctx_destroy(magma_ctx* ctx);
+int magma_ctx_info(const magma_ctx* ctx, int* h_rank, int* h_world, int* h_device);
+void* magma_ctx_stream(const magma_ctx* ctx); /* the main stream (hipStream_t) */
+
+int magma_dataset_create(magma_ctx* ctx, magma_dataset** out, int64_t M, int64_t M_total,
+                         int64_t row0, const int64_t* h_off, const double* h_t, const double* h_y,
+                         int N, const double* h_grid);
+void magma_dataset_destroy(magma_dataset* ds);
+int magma_dataset_info(const magma_dataset* ds, int64_t* h_M, int* h_nmax, int* h_N, int* h_Np);
+int magma_dataset_grid(const magma_dataset* ds, double* h_grid /* N */);
+/* device pointers of the resident results, for hosts that chain the kernel-level entry points:
+ * "mean" (Np), "cov" (Np x Np), "m0", "grid", "w", "work"; NULL for an unknown name */
+void* magma_dataset_buffer(const magma_dataset* ds, const char* name);
+int magma_get_mean(magma_ctx* ctx, magma_dataset* ds, double* h_mean /* N */);
+int magma_get_cov(magma_ctx* ctx, magma_dataset* ds, double* h_cov /* N x N, ld */, int64_t ld);
+/* load a hyper-posterior computed elsewhere (m_step / logL_* called on their own) */
+int magma_set_mean_cov(magma_ctx* ctx, magma_dataset* ds, const double* h_mean, const double* h_cov,
+                       int64_t ld);
+int magma_get_stats(const magma_dataset* ds, magma_em_stats* h_out, int reset);
+
+/* e_step (CF:371-395) on the dataset's grid with pen_diag given (CF:381: mean sigma_i; posterior_mu
+ * passes its own, MG:116): mean / cov stay resident. h_m0: n_m0 = 1 (scalar prior mean) or N values.
+ * h_info: 0 ok, > 0 K_0 not positive definite, < 0 the hyper-posterior precision; h_f0 (optional):
+ * logL_GP_mod(theta_0) at the new hyper-posterior, the theta_0 term of logL_monitoring (CF:252). */
+int magma_e_step(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0, const double* h_theta_i,
+                 int theta_stride, double pen_diag, const double* h_m0, int n_m0, int* h_info,
+                 double* h_f0);
+/* m_step (CF:397-437) against the resident hyper-posterior: theta_0 by L-BFGS-B on the side stream
+ * (its gradient's N^3 products split over the ranks), the theta_i problems inside one resident
+ * kernel (individual HPs) or one 3-parameter problem on the summed objective (common_hp). h_opt4 =
+ * (lmm, factr, pgtol, maxit) or NULL for optim's defaults (5, 1e7, 0, 100). Outputs: theta_0 (2),
+ * theta_i of ALL M_total individuals (3 M_total, gathered over the ranks). */
+int magma_m_step(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0, const double* h_theta_i,
+                 int common_hp, const double* h_opt4, double* h_theta0_out, double* h_theta_i_out);
+/* logL_monitoring (CF:236-264) at the given hyper-parameters against the resident hyper-posterior */
+int magma_logl_monitoring(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0,
+                          const double* h_theta_i, int theta_stride, double* h_out);
+/* Body of training's loop (MG:32-75): e_step, m_step, logL_monitoring(hp), logL_monitoring(new hp)
+ * -> h_logl2 (NaN, NaN when the M-step produced a NaN hyper-parameter, MG:46-51). A failed
+ * factorisation in the E-step is an error (status 5). */
+int magma_em_iteration(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0,
+                       const double* h_theta_i, const double* h_m0, int n_m0, int common_hp,
+                       const double* h_opt4, double* h_theta0_out, double* h_theta_i_out,
+                       double* h_logl2);
+/* training (MG:15-82): at most n_loop_max (reference: 25) EM iterations from ini_hp, stopping rule
+ * eps < 1e-3 (MG:64-71). h_trace3 (optional, 3 n_loop_max doubles): per iteration logLL(hp),
+ * logLL(new hp), eps -- what the reference prints at MG:56,65. The last E-step's mean / cov stay
+ * resident (`param`, MG:78). */
+int magma_training(magma_ctx* ctx, magma_dataset* ds, const double* h_m0, int n_m0,
+                   const double* h_ini_theta0, const double* h_ini_theta_i3, int common_hp,
+                   int n_loop_max, const double* h_opt4, double* h_theta0_out,
+                   double* h_theta_i_out, int* h_converged, int* h_iterations, double* h_trace3);
+/* posterior_mu (MG:107-133): the dataset on t_pred = sort(unique(db U extra timestamps)) (built
+ * here) and the E-step with `pen_diag` on it (MG:116 uses 0.1); *out keeps mean / cov resident
+ * for magma_pred_gp_resident / magma_get_*; h_N = size of t_pred (magma_dataset_grid gives it). */
+int magma_posterior_mu(magma_ctx* ctx, magma_dataset** out, int64_t M, int64_t M_total, int64_t row0,
+                       const int64_t* h_off, const double* h_t, const double* h_y, int64_t n_extra,
+                       const double* h_extra_t, const double* h_theta0, const double* h_theta_i,
+                       int theta_stride, double pen_diag, const double* h_m0_scalar, int* h_N,
+                       int* h_info);
+/* pred_gp (MG:135-181) for B new individuals against the dataset's resident hyper-posterior: host
+ * arrays in and out (ragged like magma_pred_gp_batched; timestamps are matched to the grid here:
+ * status 6 = "subscript out of bounds", as MG:161-176 index by name). */
+int magma_pred_gp_resident(magma_ctx* ctx, magma_dataset* ds, int B, const int64_t* h_off_n,
+                           const double* h_tn, const double* h_yn, const int64_t* h_off_t,
+                           const double* h_ts, const double* h_theta, int theta_stride,
+                           double* h_mean_out, double* h_var_out, int* h_info);
+/* train_new_gp (MG:84-104): 3-parameter L-BFGS-B on logL_GP / gr_GP (covariance K + new_cov) for one
+ * new individual: n <= 64 observations (ascending t), the mean process and (optional, NULL = 0)
+ * the cov block at its timestamps. h_out3 = (theta1, theta2, sigma); the initial values when the
+ * optimiser returns NaN (MG:97-101). */
+int magma_train_new_gp(magma_ctx* ctx, int n, const double* h_t, const double* h_y,
+                       const double* h_mean, const double* h_cov, int64_t ld_cov,
+                       const double* h_ini3, const double* h_opt4, double* h_out3, int* h_status);
+
 /* ---- prediction ---- */
 /* pred_gp (MG:172-180) for one new individual with n <= 64 observations and T targets.
  * mean_obs[n], mean_pred[T]: mean process at the observation / target timestamps; idx_n[n],

@@ -72,6 +72,32 @@ SIGNATURES = {
                                C.POINTER(_i64), _p]),
     "magma_indiv_mstep_resident": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _d, _i,
                                         _p, _p, _p, _p, _p, _p, _p]),
+    "magma_comm_unique_id": (_i, [_p]),
+    "magma_ctx_create": (_i, [C.POINTER(_p), _i]),
+    "magma_ctx_create_rccl": (_i, [C.POINTER(_p), _i, _i, _i, _p]),
+    "magma_ctx_create_callback": (_i, [C.POINTER(_p), _i, _i, _i, _p, _p]),
+    "magma_ctx_destroy": (None, [_p]),
+    "magma_ctx_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "magma_ctx_stream": (_p, [_p]),
+    "magma_dataset_create": (_i, [_p, C.POINTER(_p), _i64, _i64, _i64, _p, _p, _p, _i, _p]),
+    "magma_dataset_destroy": (None, [_p]),
+    "magma_dataset_info": (_i, [_p, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "magma_dataset_grid": (_i, [_p, _p]),
+    "magma_dataset_buffer": (_p, [_p, C.c_char_p]),
+    "magma_get_mean": (_i, [_p, _p, _p]),
+    "magma_get_cov": (_i, [_p, _p, _p, _i64]),
+    "magma_set_mean_cov": (_i, [_p, _p, _p, _p, _i64]),
+    "magma_get_stats": (_i, [_p, _p, _i]),
+    "magma_e_step": (_i, [_p, _p, _p, _p, _i, _d, _p, _i, C.POINTER(_i), C.POINTER(_d)]),
+    "magma_m_step": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
+    "magma_logl_monitoring": (_i, [_p, _p, _p, _p, _i, C.POINTER(_d)]),
+    "magma_em_iteration": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "magma_training": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, C.POINTER(_i),
+                            C.POINTER(_i), _p]),
+    "magma_posterior_mu": (_i, [_p, C.POINTER(_p), _i64, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p,
+                                _i, _d, _p, C.POINTER(_i), C.POINTER(_i)]),
+    "magma_pred_gp_resident": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "magma_train_new_gp": (_i, [_p, _i, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i)]),
     "magma_lbfgsb_result": (_i, [_p, _p, _p, _p, _p, _p]),
     "magma_lbfgsb_destroy": (None, [_p]),
 }

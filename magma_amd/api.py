@@ -398,7 +398,15 @@ def training(db, prior_mean, ini_hp, kern_0, kern_i, common_hp=True, trace=None,
     _check_kern(kern_0, kern_i)
     import time
     t1 = time.time()
-    eng = engine or Engine(Dataset(_as_db(db)), comm=_dist_comm())
+    if engine is None:
+        comm = _dist_comm()
+        if comm.world == 1:
+            # the whole loop inside the library: ONE call (magma_training) per fit
+            from .native import NativeEngine
+            engine = NativeEngine(Dataset(_as_db(db)))
+        else:  # ranks of a torch.distributed job: the Python-driven engine over that group
+            engine = Engine(Dataset(_as_db(db)), comm=comm)
+    eng = engine
     th0, thi, cv = eng.training(prior_mean, ini_hp["theta_0"], ini_hp["theta_i"], common_hp,
                                 trace=trace)
     return {"hp": _hp_dict(th0, thi, eng.ds.ids), "convergence": cv,

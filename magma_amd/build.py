@@ -12,8 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagma_hip.so")
-SOURCES = ["small.hip", "dense.hip", "dense_dag.hip", "capi.hip", "lbfgsb.cpp"]
-HEADERS = ["common.h", "kernels.h", "mfma_sweep.h", "dense_tile.h", "lbfgsb_core.h", os.path.join("..", "..", "include", "magma_hip.h")]
+SOURCES = ["small.hip", "dense.hip", "dense_dag.hip", "capi.hip", "driver.hip", "lbfgsb.cpp"]
+HEADERS = ["common.h", "kernels.h", "mfma_sweep.h", "dense_tile.h", "lbfgsb_core.h", "driver.h", os.path.join("..", "..", "include", "magma_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-mllvm", "-pragma-unroll-threshold=200000"]
@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -2,6 +2,7 @@
 #include "../../include/magma_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include "driver.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -87,6 +88,86 @@ static int check_small(int M, int nmax) {
   if (nmax < 1 || nmax > MAGMA_NSMALL_MAX)
     return fail(2, "n_i must be in 1..64 (one wavefront per individual)");
   return 0;
+}
+
+
+// logL_GP_mod + gr_GP_mod at theta_0 (magma_theta0_eval); sh != null: the gradient's two N^3
+// products split over ranks by block rows, the two gradient sums all-reduced (driver.h).
+int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                     const double* mean, const double* m0, const double* cov, int want_grad,
+                     void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  const int Np = ((N + 63) / 64) * 64;
+  Work wk(work, Np);
+  int rc;
+  {
+    Prof pf(PROF_COV_GRID, st);
+    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+  }
+  {
+    Prof pf(PROF_SPD_INVERSE, st);
+    if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  }
+  // alpha = K_0^-1 (mean - m0), z'alpha and sum(K_0^-1 o cov) in one pass over K_0^-1
+  if ((rc = launch_theta0_vec(N, Np, wk.A0, cov, mean, m0, wk.alpha, wk.vpart, st))) return rc;
+  if (want_grad) {
+    {
+      Prof pf(PROF_GEMM, st);
+      if (sh)
+        rc = launch_gemm_nt_rows(Np, Np, Np, wk.A0, Np, cov, Np, wk.T, Np, sh->rank, sh->world, st);
+      else
+        rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st);
+      if (rc) return rc;
+    }
+    Prof pf(PROF_CONTRACT, st);
+    if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2, wk.Z,
+                                     wk.partials, nullptr, st, sh)))
+      return rc;
+  }
+  // (f, g1, g2, info) in one device-to-host copy
+  if ((rc = launch_theta0_finish2(N, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials,
+                                  want_grad, wk.scal + 8, st)))
+    return rc;
+  if (sh && want_grad && (rc = sh->allreduce(sh->user, wk.scal + 9, 2, st))) return rc;
+  double h4[4] = {0.0, 0.0, 0.0, 0.0};
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h4, wk.scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  h_out3[0] = h4[0];
+  h_out3[1] = h4[1];
+  h_out3[2] = h4[2];
+  if (h_info) *h_info = (int)h4[3];
+  return 0;
+}
+
+int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double pen_diag,
+                      const double* mean, const double* m0, const double* cov, int m, double factr,
+                      double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,
+                      double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
+                      const Theta0Shard* sh) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  if (!h_theta0 || !h_theta_out) return fail(2, "theta0_mstep: NULL argument");
+  magma_lbfgsb* opt = magma_lbfgsb_create(1, 2, h_theta0, m, factr, pgtol, maxit);
+  if (!opt) return fail(2, "theta0_mstep: could not create the optimiser");
+  int rc = 0;
+  bool first = true;
+  for (;;) {
+    double x[2];
+    unsigned char active = 0;
+    int nact = 0;
+    if ((rc = magma_lbfgsb_ask(opt, x, &active, &nact)) || nact == 0) break;
+    double out3[3] = {0.0, 0.0, 0.0};
+    int info = 0;
+    if ((rc = theta0_eval_impl(N, grid, x[0], x[1], pen_diag, mean, m0, cov, 1, work, out3, &info, st,
+                               sh)))
+      break;
+    const double f = (info == 0) ? out3[0] : __builtin_nan("");  // not SPD: as a failed evaluation
+    if (first && h_f_x0) *h_f_x0 = f;
+    first = false;
+    if ((rc = magma_lbfgsb_tell(opt, &f, out3 + 1))) break;
+  }
+  if (!rc) rc = magma_lbfgsb_result(opt, h_theta_out, h_f_out, h_iters, h_nfev, h_status);
+  magma_lbfgsb_destroy(opt);
+  return rc;
 }
 
 }  // namespace magma
@@ -457,44 +538,8 @@ int magma_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
 int magma_theta0_eval(int N, const double* grid, double theta1, double theta2, double pen_diag,
                       const double* mean, const double* m0, const double* cov, int want_grad,
                       void* work, double* h_out3, int* h_info, void* stream) {
-  if (N < 1) return fail(2, "N must be >= 1");
-  const int Np = magma_pad(N);
-  const size_t n2 = (size_t)Np * Np;
-  hipStream_t st = S(stream);
-  Work wk(work, Np);
-  int rc;
-  {
-    Prof pf(PROF_COV_GRID, st);
-    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
-  }
-  {
-    Prof pf(PROF_SPD_INVERSE, st);
-    if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
-  }
-  // alpha = K_0^-1 (mean - m0), z'alpha and sum(K_0^-1 o cov) in one pass over K_0^-1
-  if ((rc = launch_theta0_vec(N, Np, wk.A0, cov, mean, m0, wk.alpha, wk.vpart, st))) return rc;
-  if (want_grad) {
-    {
-      Prof pf(PROF_GEMM, st);
-      if ((rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st))) return rc;
-    }
-    Prof pf(PROF_CONTRACT, st);
-    if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2,
-                                     wk.Z, wk.partials, nullptr, st)))
-      return rc;
-  }
-  // (f, g1, g2, info) in one device-to-host copy
-  if ((rc = launch_theta0_finish2(N, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials,
-                                  want_grad, wk.scal + 8, st)))
-    return rc;
-  double h4[4] = {0.0, 0.0, 0.0, 0.0};
-  MAGMA_CHECK_HIP(hipMemcpyAsync(h4, wk.scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
-  h_out3[0] = h4[0];
-  h_out3[1] = h4[1];
-  h_out3[2] = h4[2];
-  if (h_info) *h_info = (int)h4[3];
-  return 0;
+  return theta0_eval_impl(N, grid, theta1, theta2, pen_diag, mean, m0, cov, want_grad, work, h_out3,
+                          h_info, S(stream), nullptr);
 }
 
 int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double pen_diag,
@@ -502,30 +547,8 @@ int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double
                        double factr, double pgtol, int maxit, void* work, double* h_theta_out,
                        double* h_f_out, double* h_f_x0, int* h_iters, int* h_nfev, int* h_status,
                        void* stream) {
-  if (N < 1) return fail(2, "N must be >= 1");
-  if (!h_theta0 || !h_theta_out) return fail(2, "theta0_mstep: NULL argument");
-  magma_lbfgsb* opt = magma_lbfgsb_create(1, 2, h_theta0, m, factr, pgtol, maxit);
-  if (!opt) return fail(2, "theta0_mstep: could not create the optimiser");
-  int rc = 0;
-  bool first = true;
-  for (;;) {
-    double x[2];
-    unsigned char active = 0;
-    int nact = 0;
-    if ((rc = magma_lbfgsb_ask(opt, x, &active, &nact)) || nact == 0) break;
-    double out3[3] = {0.0, 0.0, 0.0};
-    int info = 0;
-    if ((rc = magma_theta0_eval(N, grid, x[0], x[1], pen_diag, mean, m0, cov, 1, work, out3, &info,
-                                stream)))
-      break;
-    const double f = (info == 0) ? out3[0] : __builtin_nan("");  // not SPD: as a failed evaluation
-    if (first && h_f_x0) *h_f_x0 = f;
-    first = false;
-    if ((rc = magma_lbfgsb_tell(opt, &f, out3 + 1))) break;
-  }
-  if (!rc) rc = magma_lbfgsb_result(opt, h_theta_out, h_f_out, h_iters, h_nfev, h_status);
-  magma_lbfgsb_destroy(opt);
-  return rc;
+  return theta0_mstep_impl(N, grid, h_theta0, pen_diag, mean, m0, cov, m, factr, pgtol, maxit, work,
+                           h_theta_out, h_f_out, h_f_x0, h_iters, h_nfev, h_status, S(stream), nullptr);
 }
 
 int magma_debug_poison_lds(void* stream) {

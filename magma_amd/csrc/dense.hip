@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "mfma_sweep.h"
 #include "dense_tile.h"
+#include "driver.h"
 
 namespace magma {
 
@@ -474,14 +475,15 @@ __global__ __launch_bounds__(256, 8) void gemm_nt_kernel(int K, double alpha,
                                                       const double* __restrict__ A, int64_t lda,
                                                       const double* __restrict__ B, int64_t ldb,
                                                       double beta, double* __restrict__ C,
-                                                      int64_t ldc) {
+                                                      int64_t ldc, int row0, int rstride) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   TileAcc acc;
   tile_zero(acc);
-  tile_gemm_nt(A + (int64_t)blockIdx.x * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc,
-               As, Bs);
-  double* Ct = C + (int64_t)blockIdx.x * NB + (int64_t)blockIdx.y * NB * ldc;
+  // block row of this workgroup: all of them (row0 = 0, rstride = 1) or one rank's share
+  const int64_t bi = row0 + (int64_t)rstride * blockIdx.x;
+  tile_gemm_nt(A + bi * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc, As, Bs);
+  double* Ct = C + bi * NB + (int64_t)blockIdx.y * NB * ldc;
   if (beta == 0.0) {
     tile_foreach(acc, [&](int m, int n, double v) { Ct[m + (int64_t)n * ldc] = alpha * v; });
   } else {
@@ -510,13 +512,15 @@ __global__ __launch_bounds__(256, 8) void gemm_nt_lower_kernel(int K, const doub
                                                                const double* __restrict__ B,
                                                                int64_t ldb, double* __restrict__ C,
                                                                int64_t ldc, int64_t cslice,
-                                                               int ks) {
+                                                               int ks,
+                                                               const int* __restrict__ plist) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   // 1-D grid over (lower tile, slice): consecutive workgroups go to different XCDs, so every XCD
   // gets the same number of (equal-sized) tasks; a 2-D grid with the upper half skipped gives
   // XCD x the block rows i = x mod 8, 52 to 80 tiles each.
-  const int z = (int)blockIdx.x % ks, p = (int)blockIdx.x / ks;
+  const int z = (int)blockIdx.x % ks;
+  const int p = plist ? plist[(int)blockIdx.x / ks] : (int)blockIdx.x / ks;  // (a rank's tiles)
   int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
   while (i * (i + 1) / 2 > p) --i;
   while ((i + 1) * (i + 2) / 2 <= p) ++i;
@@ -534,11 +538,12 @@ __global__ __launch_bounds__(256, 8) void gemm_nt_lower_kernel(int K, const doub
 __global__ __launch_bounds__(256, 8) void theta0_contract_kernel(
     int N, int Np, const double* __restrict__ Z, int zslices, int64_t zslice,
     const double* __restrict__ Kinv, const double* __restrict__ alpha,
-    const double* __restrict__ grid, double th1, double th2, double* __restrict__ partials) {
+    const double* __restrict__ grid, double th1, double th2, double* __restrict__ partials,
+    int rank, int world) {
   __shared__ double red[2][4];
   const int i = blockIdx.x, j = blockIdx.y, nt = gridDim.x;
   double* out = partials + 2 * ((int64_t)j * nt + i);
-  if (j > i) {
+  if (j > i || (i % world) != rank) {  // upper tiles by symmetry; other ranks' block rows
     if (threadIdx.x == 0) {
       out[0] = 0.0;
       out[1] = 0.0;
@@ -795,6 +800,62 @@ __global__ void theta0_finish_kernel(int N, int Np, const double* __restrict__ s
   }
 }
 
+// ------------------------------------------------------------------ driver helpers
+// (sum f, sum g0, sum g1, sum g2) over M individuals by one workgroup in a fixed order: the
+// common-HP objective (CF:203-234, 334-368) and the individual part of logL_monitoring.
+__global__ __launch_bounds__(256) void sum4_kernel(int64_t M, const double* __restrict__ f,
+                                                   const double* __restrict__ g,
+                                                   double* __restrict__ out4) {
+  __shared__ double red[4][4];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t e = threadIdx.x; e < M; e += 256) {
+    v[0] += f[e];
+    if (g != nullptr) {
+      v[1] += g[3 * e];
+      v[2] += g[3 * e + 1];
+      v[3] += g[3 * e + 2];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = wave_sum(v[q]);
+    if (lane == 0) red[q][wave] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    out4[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_lower_kernel(int Np, double* __restrict__ P,
+                                                         double* __restrict__ pack, int unpack) {
+  const int p = blockIdx.x;
+  int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (i * (i + 1) / 2 > p) --i;
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;
+  const int j = p - i * (i + 1) / 2;
+  double* tile = P + (int64_t)i * NB + (int64_t)j * NB * Np;
+  double* buf = pack + (int64_t)p * 4096;
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int m = e & 63, n = e >> 6;
+    if (unpack) tile[m + (int64_t)n * Np] = buf[e];
+    else buf[e] = tile[m + (int64_t)n * Np];
+  }
+}
+
+int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st) {
+  hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(256), 0, st, M, f, g, out4);
+  return check_hip(hipGetLastError(), "sum4");
+}
+
+int launch_pack_lower(int Np, double* P, double* pack, int unpack, hipStream_t st) {
+  const int nt = Np / NB;
+  hipLaunchKernelGGL(pack_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Np, P, pack, unpack);
+  return check_hip(hipGetLastError(), "pack_lower");
+}
+
 // ------------------------------------------------------------------ launchers
 int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2, double sigma,
                        double* A, hipStream_t st) {
@@ -841,8 +902,20 @@ int launch_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t
                    hipStream_t st) {
   if (Mr % 64 || Nc % 64 || K % 16) return fail(2, "gemm_nt: dimensions must be padded (64/64/16)");
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(Mr / 64, Nc / 64), dim3(256), 0, st, K, alpha, A, lda, B,
-                     ldb, beta, C, ldc);
+                     ldb, beta, C, ldc, 0, 1);
   return check_hip(hipGetLastError(), "gemm_nt");
+}
+
+// The block rows rank, rank + world, ... of C = A B^T only (sharded theta_0 gradient).
+int launch_gemm_nt_rows(int Mr, int Nc, int K, const double* A, int64_t lda, const double* B,
+                        int64_t ldb, double* C, int64_t ldc, int rank, int world, hipStream_t st) {
+  if (Mr % 64 || Nc % 64 || K % 16) return fail(2, "gemm_nt: dimensions must be padded (64/64/16)");
+  const int nt = Mr / 64;
+  const int rows = rank < nt ? (nt - rank + world - 1) / world : 0;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(rows, Nc / 64), dim3(256), 0, st, K, 1.0, A, lda, B, ldb, 0.0,
+                     C, ldc, rank, world);
+  return check_hip(hipGetLastError(), "gemm_nt_rows");
 }
 
 int launch_symv(int Np, const double* A, const double* x, double* yout, hipStream_t st) {
@@ -904,14 +977,17 @@ int theta0_contract_slices(int Np) {
 // Z: theta0_contract_slices(Np) * Np^2 doubles of scratch.
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
-                           double* Z, double* partials, double* out2, hipStream_t st) {
+                           double* Z, double* partials, double* out2, hipStream_t st,
+                           const Theta0Shard* sh) {
   const int nt = Np / NB;
   const int ks = theta0_contract_slices(Np);
   const int64_t n2 = (int64_t)Np * Np;
-  hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, st, Np, T,
-                     (int64_t)Np, Kinv, (int64_t)Np, Z, (int64_t)Np, n2, ks);
+  const int ntiles = sh ? sh->nplist : nt * (nt + 1) / 2;
+  if (ntiles > 0)
+    hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(ntiles * ks), dim3(256), 0, st, Np, T, (int64_t)Np,
+                       Kinv, (int64_t)Np, Z, (int64_t)Np, n2, ks, sh ? sh->plist : nullptr);
   hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, ks, n2, Kinv,
-                     alpha, grid, th1, th2, partials);
+                     alpha, grid, th1, th2, partials, sh ? sh->rank : 0, sh ? sh->world : 1);
   if (out2 != nullptr)  // (nullptr: the caller sums the per-tile pairs itself)
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, st, (int64_t)nt * nt, partials,
                        out2);

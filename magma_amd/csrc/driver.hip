@@ -1,0 +1,991 @@
+// The EM driver behind the C ABI (include/magma_hip.h, "context / dataset / driver" section):
+// `training` (MAGMA.R:15-82), `e_step` / `m_step` / `logL_monitoring` (Computing_functions.R:
+// 371-437, 236-264), `posterior_mu` (MAGMA.R:107-133), `train_new_gp` (MAGMA.R:84-104) and
+// `pred_gp` against a resident hyper-posterior, as native calls: what an R `.Call` shim, the
+// ctypes host or any other FFI reaches with ONE call per reference function, instead of one call
+// per kernel. Multi-GPU: one process (or thread) per GPU, each with its own context; partial
+// precision sums, weighted means, objective pieces and the sharded theta_0 gradient are combined
+// by an all-reduce -- RCCL (loaded at run time, never linked) or a caller-supplied callback.
+#include "../../include/magma_hip.h"
+#include "common.h"
+#include "kernels.h"
+#include "driver.h"
+
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+using namespace magma;
+
+namespace {
+
+// ------------------------------------------------------------------ RCCL, resolved at run time
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) get_id = nullptr;
+  decltype(&ncclCommInitRank) init_rank = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclCommDestroy) destroy = nullptr;
+  decltype(&ncclGetErrorString) err = nullptr;
+  bool ok = false;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // the copy the process already has (PyTorch brings its own) before any other
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+      if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!r.h)
+      for (const char* n : names)
+        if ((r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.h) return;
+    r.get_id = (decltype(r.get_id))dlsym(r.h, "ncclGetUniqueId");
+    r.init_rank = (decltype(r.init_rank))dlsym(r.h, "ncclCommInitRank");
+    r.all_reduce = (decltype(r.all_reduce))dlsym(r.h, "ncclAllReduce");
+    r.destroy = (decltype(r.destroy))dlsym(r.h, "ncclCommDestroy");
+    r.err = (decltype(r.err))dlsym(r.h, "ncclGetErrorString");
+    r.ok = r.get_id && r.init_rank && r.all_reduce && r.destroy && r.err;
+  });
+  return r;
+}
+
+int nccl_check(ncclResult_t e, const char* what) {
+  if (e == ncclSuccess) return 0;
+  return fail(200 + (int)e, std::string(what) + ": " + (rccl().err ? rccl().err(e) : "RCCL error"));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ context
+struct magma_ctx {
+  int device = 0, rank = 0, world = 1;
+  hipStream_t main = nullptr, side = nullptr;
+  ncclComm_t comm = nullptr;       // RCCL (world > 1), or
+  magma_allreduce_fn cb = nullptr;  // a caller-supplied all-reduce
+  void* cb_user = nullptr;
+  int reserve_cus = 64;  // compute units kept free of the resident M-step while theta_0 runs
+  int ncu = 256;
+
+  // sum over ranks, in place, of n doubles in device memory; ordered on `st`
+  // a communicator exists (also with world == 1: RCCL with one rank, which the single-GPU tests
+  // use to run the whole multi-rank code path)
+  bool has_comm() const { return comm != nullptr || cb != nullptr; }
+
+  int allreduce(double* d, int64_t n, hipStream_t st) {
+    if (!has_comm() || n == 0) return 0;
+    if (cb) {
+      // the callback may use its own stream / host staging: hand over finished data
+      MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+      if (int rc = cb(cb_user, d, n, (void*)st)) return fail(210, "all-reduce callback failed (" + std::to_string(rc) + ")");
+      return 0;
+    }
+    return nccl_check(rccl().all_reduce(d, d, (size_t)n, ncclFloat64, ncclSum, comm, st), "ncclAllReduce");
+  }
+};
+
+namespace magma {
+
+// ------------------------------------------------------------------ dataset
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t b) {
+    bytes = b;
+    return check_hip(hipMalloc(&p, b ? b : 8), "hipMalloc");
+  }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace magma
+
+struct magma_dataset {
+  magma_ctx* ctx = nullptr;
+  int64_t M = 0, M_total = 0, row0 = 0;
+  int nmax = 1, N = 0, Np = 0;
+  std::vector<int64_t> h_off, h_off2;
+  std::vector<double> h_t, h_y, h_grid;
+  std::vector<int> h_idx;
+  DevBuf off, off2, t, y, idx, grid;
+  DevBuf ptrP, srcP, tgtP, ptrw, srcw, tgtw, Kinv, v;
+  int64_t nP = 0, nw = 0;
+  DevBuf theta, f, g, info, sel, fsum;
+  DevBuf P, w, mean, m0, work, cpack, pack;
+  DevBuf rx, rf, rfx0, rit, rnf, rst, gath;
+  DevBuf plist;  // lower tiles of the theta_0 gradient owned by this rank
+  int nplist = 0;
+  bool cpack_ok = false, have_order = false;
+  bool a0_valid = false;
+  double a0_key[3] = {0, 0, 0};
+  std::vector<int> last_nfev;
+  // by-products of the last E-step / M-step (logL_monitoring shortcuts, MG:54,60)
+  double last_f0 = 0.0, last_sum_fi = 0.0, last_sum_fi_new = 0.0;
+  magma_em_stats stats = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+struct Opt {
+  int m = 5, maxit = 100;
+  double factr = 1e7, pgtol = 0.0;
+  explicit Opt(const double* o) {
+    if (o) {
+      m = (int)o[0];
+      factr = o[1];
+      pgtol = o[2];
+      maxit = (int)o[3];
+    }
+  }
+};
+
+int set_device(magma_ctx* c) { return check_hip(hipSetDevice(c->device), "hipSetDevice"); }
+
+template <class T>
+int upload(DevBuf& b, const std::vector<T>& h) {
+  if (int rc = b.alloc(h.size() * sizeof(T))) return rc;
+  if (h.empty()) return 0;
+  return check_hip(hipMemcpy(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice), "upload");
+}
+
+// Source lists of the deterministic E-step sums (magma_estep_gather): for every element of the
+// lower triangle of P (of w) that receives anything, the positions of its terms in the
+// materialised K_i^-1 (in v), individuals in order, each one's lower triangle column by column --
+// a counting sort by target, so the order of summation is fixed by the dataset alone.
+int build_gather_lists(magma_dataset* d) {
+  const int64_t M = d->M;
+  const int64_t Np = d->Np;
+  int64_t npairs = 0;
+  for (int64_t i = 0; i < M; ++i) {
+    const int64_t n = d->h_off[i + 1] - d->h_off[i];
+    npairs += n * (n + 1) / 2;
+  }
+  if (d->h_off2[M] >= ((int64_t)1 << 31))
+    return fail(2, "dataset: more than 2^31 matrix entries on one rank (use more ranks)");
+  // pass 1: counts per target (column-major position in P)
+  std::vector<int> cnt((size_t)Np * Np + 1, 0);
+  auto for_pairs = [&](auto&& fn) {
+    for (int64_t i = 0; i < M; ++i) {
+      const int64_t o = d->h_off[i], n = d->h_off[i + 1] - o, o2 = d->h_off2[i];
+      const int* ix = d->h_idx.data() + o;
+      for (int64_t c = 0; c < n; ++c)
+        for (int64_t r = c; r < n; ++r)  // r >= c: idx ascending, so the lower triangle of P
+          fn((int64_t)ix[r] + (int64_t)ix[c] * Np, (int)(o2 + c * n + r));
+    }
+  };
+  for_pairs([&](int64_t tg, int) { ++cnt[(size_t)tg]; });
+  std::vector<int64_t> tgt, ptr;
+  std::vector<int64_t> start((size_t)Np * Np, -1);
+  int64_t acc = 0;
+  for (int64_t e = 0; e < Np * Np; ++e)
+    if (cnt[(size_t)e]) {
+      start[(size_t)e] = acc;
+      tgt.push_back(e);
+      ptr.push_back(acc);
+      acc += cnt[(size_t)e];
+    }
+  ptr.push_back(acc);
+  std::vector<int> src((size_t)npairs);
+  for_pairs([&](int64_t tg, int s) { src[(size_t)start[(size_t)tg]++] = s; });
+  d->nP = (int64_t)tgt.size();
+  if (int rc = upload(d->ptrP, ptr)) return rc;
+  if (int rc = upload(d->srcP, src)) return rc;
+  if (int rc = upload(d->tgtP, tgt)) return rc;
+  // w: sources = positions in v (= rows of the ragged arrays), grouped by grid point
+  std::vector<int> cw((size_t)Np, 0);
+  const int64_t R = d->h_off[M];
+  for (int64_t k = 0; k < R; ++k) ++cw[(size_t)d->h_idx[(size_t)k]];
+  std::vector<int64_t> tw, pw, sw_start((size_t)Np, -1);
+  acc = 0;
+  for (int64_t e = 0; e < Np; ++e)
+    if (cw[(size_t)e]) {
+      sw_start[(size_t)e] = acc;
+      tw.push_back(e);
+      pw.push_back(acc);
+      acc += cw[(size_t)e];
+    }
+  pw.push_back(acc);
+  std::vector<int> sw((size_t)R);
+  for (int64_t k = 0; k < R; ++k) sw[(size_t)sw_start[(size_t)d->h_idx[(size_t)k]]++] = (int)k;
+  d->nw = (int64_t)tw.size();
+  if (int rc = upload(d->ptrw, pw)) return rc;
+  if (int rc = upload(d->srcw, sw)) return rc;
+  return upload(d->tgtw, tw);
+}
+
+int h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  return check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "h2d");
+}
+int d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  return check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st), "d2h");
+}
+int sync(hipStream_t st) { return check_hip(hipStreamSynchronize(st), "stream sync"); }
+
+// theta_i rows of this rank -> d->theta; returns the stride for the kernels (3, or 0 = common)
+int set_theta(magma_dataset* d, const double* h_theta_i, int stride, hipStream_t st) {
+  if (stride == 0) return h2d(d->theta.p, h_theta_i, 3 * sizeof(double), st);
+  if (d->M == 0) return 0;
+  return h2d(d->theta.p, h_theta_i + 3 * d->row0, (size_t)(3 * d->M) * sizeof(double), st);
+}
+
+int set_m0(magma_dataset* d, const double* h_m0, int n_m0, hipStream_t st) {
+  std::vector<double> v((size_t)d->Np, 0.0);
+  if (n_m0 != 1 && n_m0 != d->N) return fail(2, "m_0 must be a scalar or one value per grid point");
+  for (int k = 0; k < d->N; ++k) v[(size_t)k] = n_m0 == 1 ? h_m0[0] : h_m0[k];
+  MAGMA_CHECK_HIP(hipMemcpyAsync(d->m0.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  return sync(st);  // v goes out of scope
+}
+
+double mean_sigma(const magma_dataset* d, const double* th, int stride, double scale) {
+  if (stride == 0) return scale * th[2];
+  double s = 0.0;
+  for (int64_t i = 0; i < d->M_total; ++i) s += scale * th[3 * i + 2];
+  return s / (double)d->M_total;
+}
+
+int ensure_cpack(magma_dataset* d, hipStream_t st) {
+  if (d->cpack_ok || d->M == 0) return 0;
+  if (int rc = magma_indiv_gather_cov((int)d->M, d->nmax, d->off.as<int64_t>(), d->idx.as<int>(),
+                                      d->P.as<double>(), d->N, d->cpack.as<double>(), st))
+    return rc;
+  d->cpack_ok = true;
+  return 0;
+}
+
+// sum over this rank's individuals of f (and of the three gradient components) -> out4 (host),
+// already summed over ranks
+int sum_fi(magma_ctx* c, magma_dataset* d, const double* h_theta_i, int stride, int want_grad,
+           double* out4) {
+  hipStream_t st = c->main;
+  double* fs = d->fsum.as<double>();
+  MAGMA_CHECK_HIP(hipMemsetAsync(fs, 0, 4 * sizeof(double), st));
+  if (d->M > 0) {
+    if (int rc = set_theta(d, h_theta_i, stride, st)) return rc;
+    if (int rc = ensure_cpack(d, st)) return rc;
+    if (int rc = magma_indiv_eval(0, (int)d->M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
+                                  d->y.as<double>(), d->idx.as<int>(), d->theta.as<double>(), stride,
+                                  d->mean.as<double>(), d->cpack.as<double>(), want_grad, nullptr, 0,
+                                  d->f.as<double>(), d->g.as<double>(), d->info.as<int>(), st))
+      return rc;
+    if (want_grad) d->stats.indiv_evals += d->M;
+    if (int rc = launch_sum4(d->M, d->f.as<double>(), want_grad ? d->g.as<double>() : nullptr, fs, st))
+      return rc;
+  }
+  if (int rc = c->allreduce(fs, 4, st)) return rc;
+  if (int rc = d2h(out4, fs, 4 * sizeof(double), st)) return rc;
+  return sync(st);
+}
+
+int theta0_f(magma_ctx* c, magma_dataset* d, const double* th0, double pen, double* f_out) {
+  double out3[3];
+  int info = 0;
+  d->stats.theta0_evals += 1;
+  if (int rc = magma_theta0_eval(d->N, d->grid.as<double>(), th0[0], th0[1], pen, d->mean.as<double>(),
+                                 d->m0.as<double>(), d->P.as<double>(), 0, d->work.p, out3, &info,
+                                 c->main))
+    return rc;
+  d->a0_valid = (info == 0);
+  d->a0_key[0] = th0[0];
+  d->a0_key[1] = th0[1];
+  d->a0_key[2] = pen;
+  *f_out = info == 0 ? out3[0] : std::numeric_limits<double>::quiet_NaN();
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int magma_comm_unique_id(void* out128) {
+  if (!out128) return fail(2, "unique id: NULL buffer");
+  if (!rccl().ok) return fail(4, "RCCL is not available in this process (librccl.so could not be opened)");
+  ncclUniqueId id;
+  if (int rc = nccl_check(rccl().get_id(&id), "ncclGetUniqueId")) return rc;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+static int ctx_common(magma_ctx* c, int device) {
+  c->device = device;
+  if (int rc = set_device(c)) return rc;
+  int lo = 0, hi = 0;
+  MAGMA_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  MAGMA_CHECK_HIP(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
+  // high priority: the theta_0 chain is a long sequence of small dependent kernels that should
+  // not queue behind the wide per-individual launches it overlaps with
+  MAGMA_CHECK_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+  hipDeviceProp_t prop;
+  MAGMA_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("MAGMA_RESERVE_CUS")) c->reserve_cus = atoi(e);
+  return 0;
+}
+
+int magma_ctx_create(magma_ctx** out, int device) {
+  if (!out) return fail(2, "ctx: NULL output");
+  magma_ctx* c = new magma_ctx();
+  if (int rc = ctx_common(c, device)) {
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+int magma_ctx_create_rccl(magma_ctx** out, int device, int rank, int world, const void* unique_id128) {
+  if (!out || !unique_id128) return fail(2, "ctx: NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(2, "ctx: rank must be in 0..world-1");
+  if (!rccl().ok) return fail(4, "RCCL is not available in this process (librccl.so could not be opened)");
+  magma_ctx* c = new magma_ctx();
+  if (int rc = ctx_common(c, device)) {
+    delete c;
+    return rc;
+  }
+  c->rank = rank;
+  c->world = world;
+  {
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, sizeof(id));
+    if (int rc = nccl_check(rccl().init_rank(&c->comm, world, id, rank), "ncclCommInitRank")) {
+      delete c;
+      return rc;
+    }
+  }
+  *out = c;
+  return 0;
+}
+
+int magma_ctx_create_callback(magma_ctx** out, int device, int rank, int world,
+                              magma_allreduce_fn fn, void* user) {
+  if (!out) return fail(2, "ctx: NULL output");
+  if (world < 1 || rank < 0 || rank >= world) return fail(2, "ctx: rank must be in 0..world-1");
+  if (!fn) return fail(2, "ctx: an all-reduce callback is required");
+  magma_ctx* c = new magma_ctx();
+  if (int rc = ctx_common(c, device)) {
+    delete c;
+    return rc;
+  }
+  c->rank = rank;
+  c->world = world;
+  c->cb = fn;
+  c->cb_user = user;
+  *out = c;
+  return 0;
+}
+
+void magma_ctx_destroy(magma_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->comm && rccl().ok) (void)rccl().destroy(c->comm);
+  if (c->main) (void)hipStreamDestroy(c->main);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
+}
+
+int magma_ctx_info(const magma_ctx* c, int* rank, int* world, int* device) {
+  if (!c) return fail(2, "ctx is NULL");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (device) *device = c->device;
+  return 0;
+}
+
+void* magma_ctx_stream(const magma_ctx* c) { return c ? (void*)c->main : nullptr; }
+
+// ------------------------------------------------------------------ dataset
+int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M_total, int64_t row0,
+                         const int64_t* h_off, const double* h_t, const double* h_y, int N,
+                         const double* h_grid) {
+  if (!c || !out) return fail(2, "dataset: NULL argument");
+  if (M < 0 || M_total < M || row0 < 0 || row0 + M > M_total) return fail(2, "dataset: bad shard bounds");
+  if (N < 1 || !h_grid) return fail(2, "dataset: the union grid needs at least one point");
+  if (M > 0 && (!h_off || !h_t || !h_y)) return fail(2, "dataset: NULL arrays");
+  if (int rc = set_device(c)) return rc;
+  for (int k = 1; k < N; ++k)
+    if (!(h_grid[k] > h_grid[k - 1])) return fail(2, "dataset: the grid must be strictly ascending");
+  magma_dataset* d = new magma_dataset();
+  std::unique_ptr<magma_dataset> guard(d);
+  d->ctx = c;
+  d->M = M;
+  d->M_total = M_total;
+  d->row0 = row0;
+  d->N = N;
+  d->Np = magma_pad(N);
+  d->h_off.assign(1, 0);
+  if (M > 0) d->h_off.assign(h_off, h_off + M + 1);
+  if (d->h_off[0] != 0) return fail(2, "dataset: off[0] must be 0");
+  const int64_t R = d->h_off[(size_t)M];
+  d->h_t.assign(h_t, h_t + R);
+  d->h_y.assign(h_y, h_y + R);
+  d->h_grid.assign((size_t)d->Np, 0.0);
+  std::copy(h_grid, h_grid + N, d->h_grid.begin());
+  d->h_idx.resize((size_t)R);
+  d->h_off2.assign((size_t)M + 1, 0);
+  d->nmax = 1;
+  for (int64_t i = 0; i < M; ++i) {
+    const int64_t o = d->h_off[(size_t)i], n = d->h_off[(size_t)i + 1] - o;
+    if (n < 1) return fail(2, "dataset: every individual needs at least one observation");
+    if (n > MAGMA_NSMALL_MAX)
+      return fail(2, "dataset: an individual has more than 64 observations (one wavefront per individual)");
+    d->nmax = std::max(d->nmax, (int)n);
+    d->h_off2[(size_t)i + 1] = d->h_off2[(size_t)i] + n * n;
+    for (int64_t k = o; k < o + n; ++k) {
+      if (k > o && !(h_t[k] > h_t[k - 1]))
+        return fail(2, "dataset: timestamps must be strictly ascending within an individual");
+      // exact match on the grid: replaces the reference's `paste0('X', t)` names (CF:78,451)
+      const double* p = std::lower_bound(h_grid, h_grid + N, h_t[k]);
+      if (p == h_grid + N || *p != h_t[k]) return fail(2, "dataset: a timestamp is not on the grid");
+      d->h_idx[(size_t)k] = (int)(p - h_grid);
+    }
+  }
+  int rc;
+  if ((rc = upload(d->off, d->h_off)) || (rc = upload(d->off2, d->h_off2)) || (rc = upload(d->t, d->h_t)) ||
+      (rc = upload(d->y, d->h_y)) || (rc = upload(d->idx, d->h_idx)) || (rc = upload(d->grid, d->h_grid)))
+    return rc;
+  if ((rc = build_gather_lists(d))) return rc;
+  const size_t Mb = (size_t)std::max<int64_t>(M, 1), Np = (size_t)d->Np;
+  const size_t Mt = (size_t)std::max<int64_t>(M_total, 1);
+  const int nt = d->Np / 64;
+  if ((rc = d->Kinv.alloc(sizeof(double) * (size_t)std::max<int64_t>(d->h_off2[(size_t)M], 1))) ||
+      (rc = d->v.alloc(sizeof(double) * (size_t)std::max<int64_t>(R, 1))) ||
+      (rc = d->theta.alloc(sizeof(double) * 3 * Mb)) || (rc = d->f.alloc(sizeof(double) * Mb)) ||
+      (rc = d->g.alloc(sizeof(double) * 3 * Mb)) || (rc = d->info.alloc(sizeof(int) * Mb)) ||
+      (rc = d->sel.alloc(sizeof(int) * Mb)) || (rc = d->fsum.alloc(sizeof(double) * 16)) ||
+      (rc = d->P.alloc(sizeof(double) * Np * Np)) || (rc = d->w.alloc(sizeof(double) * Np)) ||
+      (rc = d->mean.alloc(sizeof(double) * Np)) || (rc = d->m0.alloc(sizeof(double) * Np)) ||
+      (rc = d->work.alloc(magma_workspace_bytes(N))) ||
+      (rc = d->cpack.alloc(sizeof(double) * Mb * (size_t)magma_cpack_stride(d->nmax))) ||
+      (rc = d->rx.alloc(sizeof(double) * 3 * Mb)) || (rc = d->rf.alloc(sizeof(double) * Mb)) ||
+      (rc = d->rfx0.alloc(sizeof(double) * Mb)) || (rc = d->rit.alloc(sizeof(int) * Mb)) ||
+      (rc = d->rnf.alloc(sizeof(int) * Mb)) || (rc = d->rst.alloc(sizeof(int) * Mb)))
+    return rc;
+  if (c->has_comm()) {
+    // all-reduce staging: lower 64 x 64 tiles of P, contiguous; the gathered theta_i
+    if ((rc = d->pack.alloc(sizeof(double) * (size_t)nt * (nt + 1) / 2 * 4096)) ||
+        (rc = d->gath.alloc(sizeof(double) * 3 * Mt)))
+      return rc;
+    // lower tiles (i, j <= i) of the theta_0 gradient owned by this rank: block rows
+    // i = rank, rank + world, ... (cyclic: row i has i + 1 tiles)
+    std::vector<int> pl;
+    for (int i = c->rank; i < nt; i += c->world)
+      for (int j = 0; j <= i; ++j) pl.push_back(i * (i + 1) / 2 + j);
+    d->nplist = (int)pl.size();
+    if ((rc = upload(d->plist, pl))) return rc;
+  }
+  MAGMA_CHECK_HIP(hipMemset(d->mean.p, 0, sizeof(double) * Np));
+  MAGMA_CHECK_HIP(hipMemset(d->m0.p, 0, sizeof(double) * Np));
+  *out = guard.release();
+  return 0;
+}
+
+void magma_dataset_destroy(magma_dataset* d) {
+  if (!d) return;
+  if (d->ctx) (void)hipSetDevice(d->ctx->device);
+  delete d;
+}
+
+int magma_dataset_info(const magma_dataset* d, int64_t* M, int* nmax, int* N, int* Np) {
+  if (!d) return fail(2, "dataset is NULL");
+  if (M) *M = d->M;
+  if (nmax) *nmax = d->nmax;
+  if (N) *N = d->N;
+  if (Np) *Np = d->Np;
+  return 0;
+}
+
+void* magma_dataset_buffer(const magma_dataset* d, const char* name) {
+  if (!d || !name) return nullptr;
+  const std::string s(name);
+  if (s == "mean") return d->mean.p;
+  if (s == "cov") return d->P.p;
+  if (s == "m0") return d->m0.p;
+  if (s == "grid") return d->grid.p;
+  if (s == "work") return d->work.p;
+  if (s == "w") return d->w.p;
+  return nullptr;
+}
+
+int magma_get_mean(magma_ctx* c, magma_dataset* d, double* h_mean) {
+  if (!c || !d || !h_mean) return fail(2, "get_mean: NULL argument");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = d2h(h_mean, d->mean.p, sizeof(double) * (size_t)d->N, c->main)) return rc;
+  return sync(c->main);
+}
+
+int magma_get_cov(magma_ctx* c, magma_dataset* d, double* h_cov, int64_t ld) {
+  if (!c || !d || !h_cov) return fail(2, "get_cov: NULL argument");
+  if (ld < d->N) return fail(2, "get_cov: ld < N");
+  if (int rc = set_device(c)) return rc;
+  MAGMA_CHECK_HIP(hipMemcpy2DAsync(h_cov, (size_t)ld * sizeof(double), d->P.p, (size_t)d->Np * sizeof(double),
+                                   (size_t)d->N * sizeof(double), (size_t)d->N, hipMemcpyDeviceToHost, c->main));
+  return sync(c->main);
+}
+
+int magma_set_mean_cov(magma_ctx* c, magma_dataset* d, const double* h_mean, const double* h_cov, int64_t ld) {
+  if (!c || !d || !h_mean || !h_cov) return fail(2, "set_mean_cov: NULL argument");
+  if (int rc = set_device(c)) return rc;
+  hipStream_t st = c->main;
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->mean.p, 0, sizeof(double) * (size_t)d->Np, st));
+  if (int rc = h2d(d->mean.p, h_mean, sizeof(double) * (size_t)d->N, st)) return rc;
+  if (int rc = launch_fill((int64_t)d->Np * d->Np, 0.0, d->P.as<double>(), st)) return rc;
+  if (int rc = launch_set_identity_pad(d->N, d->Np, d->P.as<double>(), st)) return rc;
+  MAGMA_CHECK_HIP(hipMemcpy2DAsync(d->P.p, (size_t)d->Np * sizeof(double), h_cov, (size_t)ld * sizeof(double),
+                                   (size_t)d->N * sizeof(double), (size_t)d->N, hipMemcpyHostToDevice, st));
+  d->cpack_ok = false;
+  return sync(st);
+}
+
+int magma_get_stats(const magma_dataset* d, magma_em_stats* out, int reset) {
+  if (!d || !out) return fail(2, "get_stats: NULL argument");
+  *out = d->stats;
+  if (reset) const_cast<magma_dataset*>(d)->stats = magma_em_stats{0, 0, 0, 0, 0};
+  return 0;
+}
+
+// ------------------------------------------------------------------ E-step (CF:371-395)
+int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
+                 int theta_stride, double pen_diag, const double* h_m0, int n_m0, int* h_info,
+                 double* h_f0) {
+  if (!c || !d || !h_theta0 || !h_theta_i || !h_m0) return fail(2, "e_step: NULL argument");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (int rc = set_device(c)) return rc;
+  hipStream_t st = c->main;
+  int rc;
+  if ((rc = set_m0(d, h_m0, n_m0, st))) return rc;
+  if ((rc = set_theta(d, h_theta_i, theta_stride, st))) return rc;
+  d->cpack_ok = false;
+  const size_t Np = (size_t)d->Np;
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->P.p, 0, sizeof(double) * Np * Np, st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->w.p, 0, sizeof(double) * Np, st));
+  if (d->M > 0 &&
+      (rc = magma_estep_gather((int)d->M, d->nmax, d->off.as<int64_t>(), d->off2.as<int64_t>(),
+                               d->t.as<double>(), d->y.as<double>(), d->theta.as<double>(), theta_stride,
+                               d->Kinv.as<double>(), d->v.as<double>(), d->f.as<double>(), d->nP,
+                               d->ptrP.as<int64_t>(), d->srcP.as<int>(), d->tgtP.as<int64_t>(), d->nw,
+                               d->ptrw.as<int64_t>(), d->srcw.as<int>(), d->tgtw.as<int64_t>(),
+                               d->P.as<double>(), d->w.as<double>(), d->info.as<int>(), st)))
+    return rc;
+  if (c->has_comm()) {
+    // partial precision sums: only the lower tiles carry anything -- packed, summed, unpacked
+    const int nt = d->Np / 64;
+    const int64_t npk = (int64_t)nt * (nt + 1) / 2 * 4096;
+    if ((rc = launch_pack_lower(d->Np, d->P.as<double>(), d->pack.as<double>(), 0, st))) return rc;
+    if ((rc = c->allreduce(d->pack.as<double>(), npk, st))) return rc;
+    if ((rc = launch_pack_lower(d->Np, d->P.as<double>(), d->pack.as<double>(), 1, st))) return rc;
+    if ((rc = c->allreduce(d->w.as<double>(), d->Np, st))) return rc;
+  }
+  const int reuse = d->a0_valid && d->a0_key[0] == h_theta0[0] && d->a0_key[1] == h_theta0[1] &&
+                    d->a0_key[2] == pen_diag;
+  int info = 0;
+  double f0 = 0.0;
+  if ((rc = magma_estep_finish(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_diag,
+                               d->m0.as<double>(), d->P.as<double>(), d->w.as<double>(),
+                               d->mean.as<double>(), d->work.p, reuse, &f0, &info, st)))
+    return rc;
+  d->a0_valid = (info == 0);
+  d->a0_key[0] = h_theta0[0];
+  d->a0_key[1] = h_theta0[1];
+  d->a0_key[2] = pen_diag;
+  d->last_f0 = f0;
+  if (d->M > 0) {  // individuals whose K_i was not positive definite (they contributed nothing)
+    std::vector<int> hi((size_t)d->M);
+    MAGMA_CHECK_HIP(hipMemcpyAsync(hi.data(), d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
+    if ((rc = sync(st))) return rc;
+    for (int v : hi) d->stats.flagged += (v != 0);
+  }
+  if (h_info) *h_info = info;
+  if (h_f0) *h_f0 = f0;
+  return 0;
+}
+
+// ------------------------------------------------------------------ logL_monitoring (CF:236-264)
+int magma_logl_monitoring(magma_ctx* c, magma_dataset* d, const double* h_theta0,
+                          const double* h_theta_i, int theta_stride, double* h_out) {
+  if (!c || !d || !h_theta0 || !h_theta_i || !h_out) return fail(2, "logl_monitoring: NULL argument");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (int rc = set_device(c)) return rc;
+  const double pen = mean_sigma(d, h_theta_i, theta_stride, 1.0);  // CF:251
+  double ll0 = 0.0, s4[4];
+  if (int rc = theta0_f(c, d, h_theta0, pen, &ll0)) return rc;
+  if (int rc = sum_fi(c, d, h_theta_i, theta_stride, 0, s4)) return rc;
+  *h_out = -ll0 - s4[0];
+  return 0;
+}
+
+// ------------------------------------------------------------------ M-step (CF:397-437)
+int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
+                 int common_hp, const double* opt4, double* h_theta0_out, double* h_theta_i_out) {
+  if (!c || !d || !h_theta0 || !h_theta_i || !h_theta0_out || !h_theta_i_out)
+    return fail(2, "m_step: NULL argument");
+  if (int rc = set_device(c)) return rc;
+  const Opt o(opt4);
+  const double pen = mean_sigma(d, h_theta_i, 3, 2.0);  // CF:409: mean(2 sigma_i)
+  hipStream_t st = c->main;
+  const int64_t M = d->M, Mt = d->M_total;
+
+  // theta_0 (CF:412-413): a few dense N x N evaluations, each a chain of small dependent
+  // kernels -- on the high-priority side stream in a helper thread, next to the theta_i problems
+  // (independent given the E-step). With several ranks the two N^3 products of its gradient are
+  // split by block rows and their two sums all-reduced per evaluation.
+  int rc0 = 0;
+  std::string err0;
+  double th0_new[2] = {h_theta0[0], h_theta0[1]};
+  int nfev0 = 0;
+  auto run0 = [&]() {
+    (void)hipSetDevice(c->device);
+    Theta0Shard sh{c->rank, c->world, d->plist.as<int>(), d->nplist,
+                   [](void* u, double* p, int64_t n, hipStream_t s) {
+                     return static_cast<magma_ctx*>(u)->allreduce(p, n, s);
+                   }, c};
+    rc0 = theta0_mstep_impl(d->N, d->grid.as<double>(), h_theta0, pen, d->mean.as<double>(),
+                            d->m0.as<double>(), d->P.as<double>(), o.m, o.factr, o.pgtol, o.maxit,
+                            d->work.p, th0_new, nullptr, nullptr, nullptr, &nfev0, nullptr, c->side,
+                            c->has_comm() ? &sh : nullptr);
+    if (rc0) err0 = magma_last_error();
+  };
+  // theta_0 and the theta_i problems overlap only when neither side needs the communicator at
+  // the same time: individual hyper-parameters (the theta_i problems exchange nothing until the
+  // end), or a single rank
+  const bool overlap = !common_hp || !c->has_comm();
+  std::thread th0;
+  if (overlap) {
+    // both streams read the hyper-posterior the E-step left on the main stream
+    if (int rc = sync(st)) return rc;
+    const bool split = !common_hp && c->reserve_cus > 0 && M > 0;
+    set_resident_max_workgroups(split ? std::max(1, c->ncu - c->reserve_cus) : 0);
+    th0 = std::thread(run0);
+  }
+  bool joined = false;
+  auto join0 = [&]() -> int {
+    if (th0.joinable()) th0.join();
+    if (!joined) {
+      joined = true;
+      set_resident_max_workgroups(0);
+      d->a0_valid = false;  // the workspace holds K_0^-1 of the last TRIAL point
+      d->stats.theta0_evals += nfev0;
+    }
+    if (rc0) return fail(rc0, err0);
+    return 0;
+  };
+  int rc = 0;
+  double sums[2] = {0.0, 0.0};
+  if (common_hp) {
+    // CF:415-420: one 3-parameter problem, objective = sum over ALL individuals
+    magma_lbfgsb* lb = magma_lbfgsb_create(1, 3, h_theta_i, o.m, o.factr, o.pgtol, o.maxit);
+    if (!lb) rc = fail(2, "m_step: bad optimiser parameters");
+    bool first = true;
+    while (!rc) {
+      double x[3];
+      unsigned char act = 0;
+      int na = 0;
+      if ((rc = magma_lbfgsb_ask(lb, x, &act, &na)) || na == 0) break;
+      double s4[4];
+      if ((rc = sum_fi(c, d, x, 0, 1, s4))) break;
+      d->stats.common_evals += 1;
+      if (first) sums[0] = s4[0];
+      first = false;
+      if ((rc = magma_lbfgsb_tell(lb, s4, s4 + 1))) break;
+    }
+    double par[3] = {0, 0, 0}, fbest = 0.0;
+    if (!rc) rc = magma_lbfgsb_result(lb, par, &fbest, nullptr, nullptr, nullptr);
+    if (lb) magma_lbfgsb_destroy(lb);
+    sums[1] = fbest;
+    if (!rc)
+      for (int64_t i = 0; i < Mt; ++i)
+        for (int q = 0; q < 3; ++q) h_theta_i_out[3 * i + q] = par[q];
+    if (!overlap && !rc) run0();
+  } else {
+    std::vector<double> hx((size_t)(3 * std::max<int64_t>(M, 1))), hf((size_t)std::max<int64_t>(M, 1)),
+        hfx0((size_t)std::max<int64_t>(M, 1));
+    std::vector<int> hnf((size_t)std::max<int64_t>(M, 1));
+    if (M > 0) {
+      do {
+        if ((rc = ensure_cpack(d, st))) break;
+        if ((rc = set_theta(d, h_theta_i, 3, st))) break;
+        const int* order = nullptr;
+        if (d->have_order && (int64_t)d->last_nfev.size() == M) {
+          // longest chains of the previous call first (they tend to stay the longest)
+          std::vector<int> perm((size_t)M);
+          std::iota(perm.begin(), perm.end(), 0);
+          std::stable_sort(perm.begin(), perm.end(),
+                           [&](int a, int b) { return d->last_nfev[(size_t)a] > d->last_nfev[(size_t)b]; });
+          if ((rc = check_hip(hipMemcpy(d->sel.p, perm.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice),
+                              "m_step order")))
+            break;
+          order = d->sel.as<int>();
+        }
+        if ((rc = magma_indiv_mstep_resident(0, (int)M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
+                                             d->y.as<double>(), d->idx.as<int>(), d->mean.as<double>(),
+                                             d->cpack.as<double>(), d->theta.as<double>(), order, o.m,
+                                             o.factr, o.pgtol, o.maxit, d->rx.as<double>(),
+                                             d->rf.as<double>(), d->rfx0.as<double>(), d->rit.as<int>(),
+                                             d->rnf.as<int>(), d->rst.as<int>(), st)))
+          break;
+        if ((rc = d2h(hx.data(), d->rx.p, sizeof(double) * 3 * (size_t)M, st)) ||
+            (rc = d2h(hf.data(), d->rf.p, sizeof(double) * (size_t)M, st)) ||
+            (rc = d2h(hfx0.data(), d->rfx0.p, sizeof(double) * (size_t)M, st)) ||
+            (rc = d2h(hnf.data(), d->rnf.p, sizeof(int) * (size_t)M, st)) || (rc = sync(st)))
+          break;
+        d->last_nfev = hnf;
+        d->have_order = true;
+        int mx = 0;
+        for (int64_t i = 0; i < M; ++i) {
+          sums[0] += hfx0[(size_t)i];
+          sums[1] += hf[(size_t)i];
+          d->stats.indiv_evals += hnf[(size_t)i];
+          mx = std::max(mx, hnf[(size_t)i]);
+        }
+        d->stats.indiv_rounds += mx;
+      } while (false);
+    }
+    // the theta_0 thread may still be using the communicator: wait for it before this thread does
+    if (int r2 = join0()) rc = rc ? rc : r2;
+    if (!rc && c->has_comm()) {
+      double* gb = d->gath.as<double>();
+      rc = check_hip(hipMemsetAsync(gb, 0, sizeof(double) * 3 * (size_t)Mt, st), "m_step gather");
+      if (!rc && M > 0) rc = h2d(gb + 3 * d->row0, hx.data(), sizeof(double) * 3 * (size_t)M, st);
+      if (!rc) rc = c->allreduce(gb, 3 * Mt, st);
+      if (!rc) rc = d2h(h_theta_i_out, gb, sizeof(double) * 3 * (size_t)Mt, st);
+      double* fs = d->fsum.as<double>();
+      if (!rc) rc = h2d(fs, sums, 2 * sizeof(double), st);
+      if (!rc) rc = c->allreduce(fs, 2, st);
+      if (!rc) rc = d2h(sums, fs, 2 * sizeof(double), st);
+      if (!rc) rc = sync(st);
+    } else if (!rc) {
+      std::copy(hx.begin(), hx.begin() + 3 * M, h_theta_i_out);
+    }
+  }
+  if (int r2 = join0()) rc = rc ? rc : r2;
+  if (rc) return rc;
+  d->last_sum_fi = sums[0];
+  d->last_sum_fi_new = sums[1];
+  h_theta0_out[0] = th0_new[0];
+  h_theta0_out[1] = th0_new[1];
+  return 0;
+}
+
+// ------------------------------------------------------------------ one EM iteration (MG:32-75)
+int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
+                       const double* h_m0, int n_m0, int common_hp, const double* opt4,
+                       double* h_theta0_out, double* h_theta_i_out, double* h_logl2) {
+  if (!c || !d || !h_logl2) return fail(2, "em_iteration: NULL argument");
+  const double nanv = std::numeric_limits<double>::quiet_NaN();
+  const double pen_e = mean_sigma(d, h_theta_i, 3, 1.0);  // CF:381 (signed mean)
+  int info = 0;
+  if (int rc = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr)) return rc;
+  if (info != 0)
+    return fail(5, std::string("E-step: ") + (info > 0 ? "K_0" : "hyper-posterior precision") +
+                       " not positive definite (info=" + std::to_string(info) + ")");
+  if (int rc = magma_m_step(c, d, h_theta0, h_theta_i, common_hp, opt4, h_theta0_out, h_theta_i_out))
+    return rc;
+  bool bad = std::isnan(h_theta0_out[0]) || std::isnan(h_theta0_out[1]);
+  for (int64_t k = 0; k < 3 * d->M_total && !bad; ++k) bad = std::isnan(h_theta_i_out[k]);
+  if (bad) {  // MG:46-51
+    h_logl2[0] = h_logl2[1] = nanv;
+    return 0;
+  }
+  // logL_monitoring(hp) (MG:54) from by-products: its theta_0 term came out of the E-step's
+  // K_0^-1 (same theta_0, same pen_diag: CF:251, 381), its individual terms are the optimisers'
+  // first evaluations. logL_monitoring(new hp) (MG:60): individual terms = the optimisers' final
+  // values; only the theta_0 term needs an evaluation, which leaves K_0^-1 for the next E-step.
+  h_logl2[0] = -d->last_f0 - d->last_sum_fi;
+  const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
+  double ll0 = 0.0;
+  if (int rc = theta0_f(c, d, h_theta0_out, sig, &ll0)) return rc;
+  h_logl2[1] = -ll0 - d->last_sum_fi_new;
+  return 0;
+}
+
+// ------------------------------------------------------------------ training (MG:15-82)
+int magma_training(magma_ctx* c, magma_dataset* d, const double* h_m0, int n_m0,
+                   const double* ini_theta0, const double* ini_theta_i3, int common_hp,
+                   int n_loop_max, const double* opt4, double* h_theta0_out, double* h_theta_i_out,
+                   int* h_converged, int* h_iterations, double* h_trace3) {
+  if (!c || !d || !h_m0 || !ini_theta0 || !ini_theta_i3 || !h_theta0_out || !h_theta_i_out)
+    return fail(2, "training: NULL argument");
+  const int64_t Mt = d->M_total;
+  std::vector<double> thi((size_t)(3 * Mt)), nthi((size_t)(3 * Mt));
+  for (int64_t i = 0; i < Mt; ++i)
+    for (int q = 0; q < 3; ++q) thi[(size_t)(3 * i + q)] = ini_theta_i3[q];  // MG:26-27
+  double th0[2] = {ini_theta0[0], ini_theta0[1]}, nth0[2];
+  int cv = 0, it = 0;
+  for (it = 1; it <= n_loop_max; ++it) {  // MG:32
+    double ll[2];
+    if (int rc = magma_em_iteration(c, d, th0, thi.data(), h_m0, n_m0, common_hp, opt4, nth0,
+                                    nthi.data(), ll))
+      return rc;
+    if (std::isnan(ll[0])) break;  // MG:46-51: keep the last valid iteration
+    const double eps = (ll[1] - ll[0]) / std::fabs(ll[1]);  // MG:64
+    if (h_trace3) {
+      h_trace3[3 * (it - 1) + 0] = ll[0];
+      h_trace3[3 * (it - 1) + 1] = ll[1];
+      h_trace3[3 * (it - 1) + 2] = eps;
+    }
+    if (eps < 1e-3) {  // MG:66-71
+      if (eps > 0) {
+        th0[0] = nth0[0];
+        th0[1] = nth0[1];
+        thi.swap(nthi);
+      }
+      cv = 1;
+      break;
+    }
+    th0[0] = nth0[0];
+    th0[1] = nth0[1];
+    thi.swap(nthi);
+  }
+  h_theta0_out[0] = th0[0];
+  h_theta0_out[1] = th0[1];
+  std::copy(thi.begin(), thi.end(), h_theta_i_out);
+  if (h_converged) *h_converged = cv;
+  if (h_iterations) *h_iterations = std::min(it, n_loop_max);
+  return 0;
+}
+
+// ------------------------------------------------------------------ posterior_mu (MG:107-133)
+int magma_posterior_mu(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M_total, int64_t row0,
+                       const int64_t* h_off, const double* h_t, const double* h_y, int64_t n_extra,
+                       const double* h_extra_t, const double* h_theta0, const double* h_theta_i,
+                       int theta_stride, double pen_diag, const double* h_m0_scalar, int* h_N,
+                       int* h_info) {
+  if (!c || !out || !h_theta0 || !h_theta_i || !h_m0_scalar) return fail(2, "posterior_mu: NULL argument");
+  // t_pred = sort(unique(timestamps U db U new_db)) (MG:114)
+  std::vector<double> grid;
+  const int64_t R = M > 0 ? h_off[M] : 0;
+  grid.reserve((size_t)(R + n_extra));
+  grid.insert(grid.end(), h_t, h_t + R);
+  if (n_extra > 0) grid.insert(grid.end(), h_extra_t, h_extra_t + n_extra);
+  std::sort(grid.begin(), grid.end());
+  grid.erase(std::unique(grid.begin(), grid.end()), grid.end());
+  if (grid.empty()) return fail(2, "posterior_mu: no timestamps");
+  magma_dataset* d = nullptr;
+  if (int rc = magma_dataset_create(c, &d, M, M_total, row0, h_off, h_t, h_y, (int)grid.size(), grid.data()))
+    return rc;
+  int info = 0;
+  if (int rc = magma_e_step(c, d, h_theta0, h_theta_i, theta_stride, pen_diag, h_m0_scalar, 1, &info, nullptr)) {
+    magma_dataset_destroy(d);
+    return rc;
+  }
+  if (h_N) *h_N = (int)grid.size();
+  if (h_info) *h_info = info;
+  *out = d;
+  return 0;
+}
+
+int magma_dataset_grid(const magma_dataset* d, double* h_grid) {
+  if (!d || !h_grid) return fail(2, "dataset_grid: NULL argument");
+  std::copy(d->h_grid.begin(), d->h_grid.begin() + d->N, h_grid);
+  return 0;
+}
+
+// ------------------------------------------------------------------ pred_gp against a resident
+// hyper-posterior (MG:135-181 for B new individuals; host arrays in, host arrays out)
+int magma_pred_gp_resident(magma_ctx* c, magma_dataset* d, int B, const int64_t* h_off_n,
+                           const double* h_tn, const double* h_yn, const int64_t* h_off_t,
+                           const double* h_ts, const double* h_theta, int theta_stride,
+                           double* h_mean_out, double* h_var_out, int* h_info) {
+  if (!c || !d || !h_off_n || !h_off_t || !h_theta) return fail(2, "pred_gp_resident: NULL argument");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (B <= 0) return 0;
+  if (int rc = set_device(c)) return rc;
+  const int64_t Rn = h_off_n[B], Rt = h_off_t[B];
+  int nmax = 1, tmax = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = h_off_n[b + 1] - h_off_n[b], T = h_off_t[b + 1] - h_off_t[b];
+    if (n < 1 || n > MAGMA_NSMALL_MAX) return fail(2, "pred_gp_resident: 1 <= n_b <= 64 observations per individual");
+    nmax = std::max(nmax, (int)n);
+    tmax = std::max(tmax, (int)T);
+  }
+  std::vector<int> in((size_t)Rn), it((size_t)std::max<int64_t>(Rt, 1));
+  const double* g0 = d->h_grid.data();
+  auto on_grid = [&](double x, int& pos) {
+    const double* p = std::lower_bound(g0, g0 + d->N, x);
+    if (p == g0 + d->N || *p != x) return false;
+    pos = (int)(p - g0);
+    return true;
+  };
+  for (int64_t k = 0; k < Rn; ++k)
+    if (!on_grid(h_tn[k], in[(size_t)k])) return fail(6, "pred_gp_resident: subscript out of bounds (an observation timestamp is not on the grid)");
+  for (int64_t k = 0; k < Rt; ++k)
+    if (!on_grid(h_ts[k], it[(size_t)k])) return fail(6, "pred_gp_resident: subscript out of bounds (a target timestamp is not on the grid)");
+  DevBuf on, tn, yn, dn, ot, ts, dt, th, om, ov, di;
+  const size_t nth = theta_stride ? (size_t)3 * B : 3;
+  int rc;
+  if ((rc = on.alloc(sizeof(int64_t) * (B + 1))) || (rc = tn.alloc(sizeof(double) * Rn)) ||
+      (rc = yn.alloc(sizeof(double) * Rn)) || (rc = dn.alloc(sizeof(int) * Rn)) ||
+      (rc = ot.alloc(sizeof(int64_t) * (B + 1))) || (rc = ts.alloc(sizeof(double) * std::max<int64_t>(Rt, 1))) ||
+      (rc = dt.alloc(sizeof(int) * std::max<int64_t>(Rt, 1))) || (rc = th.alloc(sizeof(double) * nth)) ||
+      (rc = om.alloc(sizeof(double) * std::max<int64_t>(Rt, 1))) ||
+      (rc = ov.alloc(sizeof(double) * std::max<int64_t>(Rt, 1))) || (rc = di.alloc(sizeof(int) * B)))
+    return rc;
+  hipStream_t st = c->main;
+  if ((rc = h2d(on.p, h_off_n, sizeof(int64_t) * (B + 1), st)) || (rc = h2d(tn.p, h_tn, sizeof(double) * Rn, st)) ||
+      (rc = h2d(yn.p, h_yn, sizeof(double) * Rn, st)) || (rc = h2d(dn.p, in.data(), sizeof(int) * Rn, st)) ||
+      (rc = h2d(ot.p, h_off_t, sizeof(int64_t) * (B + 1), st)) ||
+      (Rt > 0 && (rc = h2d(ts.p, h_ts, sizeof(double) * Rt, st))) ||
+      (Rt > 0 && (rc = h2d(dt.p, it.data(), sizeof(int) * Rt, st))) ||
+      (rc = h2d(th.p, h_theta, sizeof(double) * nth, st)))
+    return rc;
+  MAGMA_CHECK_HIP(hipMemsetAsync(di.p, 0, sizeof(int) * B, st));
+  if ((rc = magma_pred_gp_batched(B, nmax, tmax, on.as<int64_t>(), tn.as<double>(), yn.as<double>(),
+                                  dn.as<int>(), ot.as<int64_t>(), ts.as<double>(), dt.as<int>(),
+                                  d->mean.as<double>(), d->P.as<double>(), d->N, th.as<double>(),
+                                  theta_stride, om.as<double>(), ov.as<double>(), di.as<int>(), st)))
+    return rc;
+  if (Rt > 0 && ((rc = d2h(h_mean_out, om.p, sizeof(double) * Rt, st)) ||
+                 (rc = d2h(h_var_out, ov.p, sizeof(double) * Rt, st))))
+    return rc;
+  if (h_info && (rc = d2h(h_info, di.p, sizeof(int) * B, st))) return rc;
+  return sync(st);
+}
+
+// ------------------------------------------------------------------ train_new_gp (MG:84-104)
+int magma_train_new_gp(magma_ctx* c, int n, const double* h_t, const double* h_y, const double* h_mean,
+                       const double* h_cov, int64_t ld_cov, const double* ini3, const double* opt4,
+                       double* h_out3, int* h_status) {
+  if (!c || !h_t || !h_y || !h_mean || !ini3 || !h_out3) return fail(2, "train_new_gp: NULL argument");
+  if (n < 1 || n > MAGMA_NSMALL_MAX) return fail(2, "train_new_gp: n must be in 1..64");
+  if (int rc = set_device(c)) return rc;
+  const Opt o(opt4);
+  // one individual whose grid is its own timestamps: mean / new_cov given on that grid
+  std::vector<int64_t> off = {0, n};
+  magma_dataset* d = nullptr;
+  if (int rc = magma_dataset_create(c, &d, 1, 1, 0, off.data(), h_t, h_y, n, h_t)) return rc;
+  std::unique_ptr<magma_dataset, void (*)(magma_dataset*)> guard(d, magma_dataset_destroy);
+  std::vector<double> zero;
+  if (!h_cov) {
+    zero.assign((size_t)n * n, 0.0);
+    h_cov = zero.data();
+    ld_cov = n;
+  }
+  if (int rc = magma_set_mean_cov(c, d, h_mean, h_cov, ld_cov)) return rc;
+  hipStream_t st = c->main;
+  if (int rc = ensure_cpack(d, st)) return rc;
+  double x[3], f = 0.0;
+  int status = 0;
+  if (int rc = magma_indiv_mstep(1, 1, d->nmax, d->off.as<int64_t>(), d->t.as<double>(), d->y.as<double>(),
+                                 d->idx.as<int>(), d->mean.as<double>(), d->cpack.as<double>(), ini3, o.m,
+                                 o.factr, o.pgtol, o.maxit, d->theta.as<double>(), d->sel.as<int>(),
+                                 d->f.as<double>(), d->g.as<double>(), d->info.as<int>(), x, &f, nullptr,
+                                 nullptr, nullptr, &status, nullptr, nullptr, st))
+    return rc;
+  const bool bad = std::isnan(x[0]) || std::isnan(x[1]) || std::isnan(x[2]);  // MG:97-101
+  for (int q = 0; q < 3; ++q) h_out3[q] = bad ? ini3[q] : x[q];
+  if (h_status) *h_status = status;
+  return 0;
+}
+
+}  // extern "C"

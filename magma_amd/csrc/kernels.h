@@ -66,9 +66,13 @@ int launch_symv(int Np, const double* A, const double* x, double* yout, hipStrea
 int launch_axpy(int64_t n, double alpha, const double* x, double* yio, hipStream_t st);
 int launch_dot(int64_t n, const double* a, const double* b, double* partial, double* out,
                hipStream_t st);
+struct Theta0Shard;
+int launch_gemm_nt_rows(int Mr, int Nc, int K, const double* A, int64_t lda, const double* B,
+                        int64_t ldb, double* C, int64_t ldc, int rank, int world, hipStream_t st);
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
-                           double* Z, double* partials, double* out2, hipStream_t st);
+                           double* Z, double* partials, double* out2, hipStream_t st,
+                           const Theta0Shard* sh = nullptr);
 int theta0_vec_blocks(int Np);
 int launch_theta0_vec(int N, int Np, const double* Kinv, const double* cov, const double* mean,
                       const double* m0, double* alpha, double* vpart, hipStream_t st);

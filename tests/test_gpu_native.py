@@ -1,0 +1,326 @@
+"""The native EM driver behind the C ABI (magma_ctx / magma_dataset / magma_training, ...: the
+reference's `training`, `e_step`, `m_step`, `logL_monitoring`, `posterior_mu`, `train_new_gp`
+as ONE library call each, MAGMA.R:15-133, Computing_functions.R:236-264, 371-437), driven through
+ctypes only (magma_amd.native is pointer plumbing):
+  * `magma_training` reproduces the hyper-parameters R stored in train_FT.rds (1e-7) and equals
+    the Python-driven engine on the same kernels;
+  * one EM iteration equals the Python-driven `Engine` (bit for bit where the order of summation
+    is the same) and the oracle;
+  * several ranks (threads on one GPU, all-reduce through the library's callback communicator)
+    equal one rank: packed all-reduce of the precision, gathered theta_i, and the theta_0
+    gradient whose N^3 products are split over the ranks by block rows;
+  * posterior_mu / pred_gp / train_new_gp through their native entry points against the oracle.
+"""
+import threading
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import magma_oracle as orc  # noqa: E402  (checker only)
+from kat_common import dataset, hp_of  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def m():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
+    import magma_amd
+    return magma_amd
+
+
+def _ragged_db(rng, sizes, tmax=10.0, step=0.05):
+    grid = np.arange(0.0, tmax + 1e-9, step)
+    ids, ts, ys = [], [], []
+    for k, n in enumerate(sizes):
+        t = np.sort(rng.choice(grid, n, replace=False))
+        ids += [k + 1] * n
+        ts.append(t)
+        ys.append(rng.normal(0, 2, n) + 0.5 * t)
+    return {"ID": np.array(ids), "Timestamp": np.concatenate(ts), "Output": np.concatenate(ys)}
+
+
+@pytest.mark.parametrize("d", [1, 2, 4])
+def test_native_training_reproduces_stored_model(m, d):
+    """Only `magma_training` is called (plus the dataset / context constructors)."""
+    from magma_amd.native import NativeEngine
+    _, _, train = dataset("data_FT", d)
+    eng = NativeEngine(m.Dataset(train))
+    trace = []
+    th0, thi, cv = eng.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=True, trace=trace)
+    ref = hp_of("hp_FT", d)
+    assert cv and len(trace) >= 2 and trace[-1]["eps"] < 1e-3
+    assert np.abs(th0 - ref["theta_0"]).max() < 1e-7, (th0, ref["theta_0"])
+    for k, i in enumerate(eng.ds.ids):
+        assert np.abs(thi[k] - ref["theta_i"][int(i)]).max() < 1e-7
+    # the last E-step's hyper-posterior stays resident (`param`, MG:78): equals the oracle's
+    # E-step at the hyper-parameters that E-step saw (those of the previous iteration)
+    assert eng.get_cov().shape == (eng.N, eng.N) and np.all(np.isfinite(eng.get_mean()))
+    eng.close()
+
+
+@pytest.mark.parametrize("common", [False, True], ids=["individual-hp", "common-hp"])
+@pytest.mark.parametrize("sizes", [[30] * 12, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50]],
+                         ids=["uniform", "ragged"])
+def test_native_em_iteration_equals_python_engine_and_oracle(m, sizes, common):
+    from magma_amd.native import NativeEngine
+    rng = np.random.default_rng(len(sizes))
+    db = _ragged_db(rng, sizes)
+    ds = m.Dataset(db)
+    th0 = np.array([0.9, 0.7])
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+    if not common:  # (with common HPs `training` keeps every row equal, MG:26-27, CF:420)
+        thi = thi + rng.uniform(-0.3, 0.3, size=(ds.M, 3))
+    nat, py = NativeEngine(ds), m.Engine(ds)
+    pen = float(np.mean(thi[:, 2]))
+    assert nat.e_step(th0, thi, pen, 0.4) == 0 and py.e_step(th0, thi, pen, 0.4) == 0
+    c_n, c_p = nat.get_cov(), py.be.get_cov()
+    uniform = len(set(sizes)) == 1
+    if uniform:  # same order of summation in both list builders -> same bits
+        assert np.array_equal(c_n, c_p) and np.array_equal(nat.get_mean(), py.be.get_mean())
+        assert nat.last_f0 == py.last_f0
+    else:
+        assert np.abs(c_n - c_p).max() < 1e-10 * np.abs(c_p).max()
+    hp = {"theta_0": th0, "theta_i": {i: thi[k] for k, i in enumerate(ds.ids)}}
+    exp = orc.e_step(db, 0.4, orc.kernel, orc.kernel, hp)
+    assert np.abs(c_n - exp["cov"][1]).max() < 1e-9 * np.abs(exp["cov"][1]).max()
+    a = nat.em_iteration(th0, thi, 0.4, common)
+    b = py.em_iteration(th0, thi, 0.4, common)
+    # Same kernels, same optimiser source; what differs is host arithmetic in the last bit (mean
+    # sigma_i and the sums over individuals: NumPy's pairwise order against a plain loop, and for
+    # common HPs a device-side sum), which the optimisers' paths amplify a little.
+    dth = np.abs(a[1] - b[1])
+    assert np.abs(a[0] - b[0]).max() < 1e-6 and np.median(dth) < 1e-8 and dth.max() < 1e-3
+    assert abs(a[2] - b[2]) < 1e-12 * abs(b[2]) and abs(a[3] - b[3]) < 1e-9 * abs(b[3])
+    ll = orc.logL_monitoring(hp, db, orc.kernel, orc.kernel, exp["mean"], exp["cov"], 0.4)
+    assert abs(a[2] - ll) < 1e-9 * abs(ll)
+    hp_n = {"theta_0": a[0], "theta_i": {i: a[1][k] for k, i in enumerate(ds.ids)}}
+    ll_n = orc.logL_monitoring(hp_n, db, orc.kernel, orc.kernel, exp["mean"], exp["cov"], 0.4)
+    assert abs(a[3] - ll_n) < 1e-9 * abs(ll_n)
+    assert abs(nat.logL_monitoring(a[0], a[1]) - ll_n) < 1e-9 * abs(ll_n)
+    if common:
+        assert np.all(a[1] == a[1][0]) and nat.stats["common_evals"] > 0
+    else:
+        assert nat.stats["indiv_evals"] >= ds.M and nat.stats["theta0_evals"] >= 2
+    nat.close()
+
+
+def test_native_training_individual_hp_equals_python_engine(m):
+    from magma_amd.native import NativeEngine
+    _, _, train = dataset("data_FF", 1)
+    ds = m.Dataset(train)
+    nat, py = NativeEngine(ds), m.Engine(ds)
+    t_n, t_p = [], []
+    a = nat.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_n)
+    b = py.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_p)
+    assert a[2] == b[2] and len(t_n) == len(t_p)
+    # (last-bit differences of the host sums, amplified over ~6 EM iterations of 20 optimisations)
+    assert np.abs(a[0] - b[0]).max() < 1e-6 and np.abs(a[1] - b[1]).max() < 1e-4
+    for x, y in zip(t_n, t_p):
+        assert abs(x["logLL"] - y["logLL"]) <= 1e-9 * abs(y["logLL"])
+    ref = hp_of("hp_FF", 1)  # at optimiser tolerance (see test_gpu_kat)
+    assert np.abs(a[0] - ref["theta_0"]).max() < 1e-3
+    nat.close()
+
+
+# ------------------------------------------------------------------ several ranks on one GPU
+class _Shared:
+    def __init__(self, world):
+        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+
+
+def _make_allreduce(shared, rank):
+    from magma_amd.native import device_tensor
+
+    def allreduce(ptr, count):
+        import torch
+        t = device_tensor(ptr, count)
+        shared.slots[rank] = t.clone()
+        torch.cuda.synchronize()
+        shared.barrier.wait()
+        parts = list(shared.slots)
+        t.zero_()
+        for p in parts:  # rank order on every rank: identical bits everywhere
+            t.add_(p)
+        torch.cuda.synchronize()
+        shared.barrier.wait()
+    return allreduce
+
+
+def _run_ranks(ds, world, fn):
+    import torch
+    from magma_amd.native import NativeEngine
+    shared = _Shared(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            eng = NativeEngine(ds, rank=r, world=world, allreduce=_make_allreduce(shared, r))
+            out[r] = fn(eng)
+            eng.close()
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared.barrier.abort()
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+@pytest.mark.parametrize("world,N", [(2, 200), (3, 450), (4, 2000)])
+def test_native_ranks_as_threads_equal_one_rank(m, world, N):
+    """Callback communicator: the sharded E-step (lower tiles of P packed for the all-reduce), the
+    theta_0 M-step with its gradient products split by block rows, the gathered theta_i."""
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_arrays
+    M = 403  # not a multiple of any world size here: ragged shards, one possibly short
+    a = simu_arrays(M, 30, N, seed=77)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    th0 = np.array([1.0, 1.0])
+    thi = np.tile([1.0, 1.0, 0.2], (M, 1))
+    one = NativeEngine(ds)
+    assert one.e_step(th0, thi, 0.2, 0.3) == 0
+    post = (one.get_mean(), one.get_cov())
+
+    def job(eng):
+        info = eng.e_step(th0, thi, 0.2, 0.3)
+        out = dict(info=info, mean=eng.get_mean(), cov=eng.get_cov(), f0=eng.last_f0)
+        eng.set_mean_cov(*post)  # bit-identical hyper-posterior for the M-step comparison
+        out["n0"], out["ni"] = eng.m_step(th0, thi, False)
+        out["mon"] = eng.logL_monitoring(out["n0"], out["ni"])
+        out["n0c"], out["nic"] = eng.m_step(th0, thi, True)
+        out["em"] = eng.em_iteration(th0, thi, 0.3, False)
+        return out
+    ref = job(one)
+    res = _run_ranks(ds, world, job)
+    rel = lambda x, y: float(np.abs(np.asarray(x) - np.asarray(y)).max() / np.abs(np.asarray(y)).max())  # noqa: E731
+    for r in res:
+        assert r["info"] == 0
+        assert rel(r["cov"], ref["cov"]) < 1e-12 and rel(r["mean"], ref["mean"]) < 1e-12
+        assert rel(r["f0"], ref["f0"]) < 1e-12
+        for k in ("n0", "ni", "n0c", "nic"):  # replicated results are the same bits on every rank
+            assert np.array_equal(r[k], res[0][k]), k
+        assert r["mon"] == res[0]["mon"] and r["em"][2] == res[0]["em"][2]
+    r0 = res[0]
+    # theta_i: every individual's problem has the same inputs whichever rank runs it
+    assert np.array_equal(r0["ni"], ref["ni"])
+    # theta_0: same objective; the two gradient sums are added in another order (block rows per
+    # rank, then ranks) -> rounding-level differences, amplified a little by the optimiser
+    assert np.abs(r0["n0"] - ref["n0"]).max() < 1e-6, (r0["n0"], ref["n0"])
+    assert rel(r0["mon"], ref["mon"]) < 1e-9
+    assert np.abs(r0["n0c"] - ref["n0c"]).max() < 1e-6 and np.abs(r0["nic"] - ref["nic"]).max() < 1e-5
+    # whole iteration: hyper-posteriors that differ by rounding, then ~400 optimisations
+    assert rel(r0["em"][2], ref["em"][2]) < 1e-12 and rel(r0["em"][3], ref["em"][3]) < 1e-4
+    one.close()
+
+
+def test_sharded_theta0_gradient_equals_unsharded(m):
+    """One theta_0 evaluation with its products split 1-, 2-, 5-ways agrees to summation order:
+    checked through the M-step's first iterate with maxit = 1 (the optimiser's first step is a
+    fixed multiple of the gradient at the start)."""
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(64, 30, 700, seed=5)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    th0, thi = np.array([1.2, 0.6]), np.tile([1.0, 1.0, 0.3], (64, 1))
+
+    def job(eng):
+        assert eng.e_step(th0, thi, 0.3, 0.0) == 0
+        return eng.m_step(th0, thi, False, {"maxit": 1})[0]
+    one = NativeEngine(ds)
+    ref = job(one)
+    one.close()
+    for world in (2, 5):
+        for r in _run_ranks(ds, world, job):
+            assert np.abs(r - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), (world, r, ref)
+
+
+def test_rccl_communicator_with_one_rank(m):
+    """RCCL itself on the one GPU of this box: unique id, ncclCommInitRank (one rank), and every
+    all-reduce of an EM iteration going through ncclAllReduce -- packed precision tiles, weighted
+    mean, the sharded theta_0 gradient sums (here: all block rows on rank 0), gathered theta_i.
+    With one rank the sums are identities, so the result must equal the communicator-free run."""
+    from magma_amd.native import NativeEngine, unique_id
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(200, 30, 500, seed=3)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    th0, thi = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (200, 1))
+    uid = unique_id()
+    assert len(uid) == 128 and any(uid)
+    plain, rccl = NativeEngine(ds), NativeEngine(ds, rank=0, world=1, unique_id=uid)
+    for common in (False, True):
+        x = plain.em_iteration(th0, thi, 0.2, common)
+        y = rccl.em_iteration(th0, thi, 0.2, common)
+        assert np.array_equal(plain.get_cov(), rccl.get_cov())
+        assert np.array_equal(x[1], y[1]) and x[2] == y[2]
+        # theta_0: the sharded route sums the same per-tile pairs in the same order
+        assert np.abs(x[0] - y[0]).max() < 1e-9 and abs(x[3] - y[3]) < 1e-10 * abs(x[3])
+    plain.close()
+    rccl.close()
+
+
+# ------------------------------------------------------------------ prediction side
+def test_native_posterior_mu_pred_gp_and_train_new_gp(m):
+    import ctypes as C
+    from magma_amd import _lib
+    from magma_amd.native import train_new_gp
+    truth, test, train = dataset("data_FT", 7)
+    hp = hp_of("hp_FT", 7)
+    ds = m.Dataset(train)
+    th0 = hp["theta_0"]
+    thi = np.array([hp["theta_i"][int(i)] for i in ds.ids])
+    db_obs = {k: v[:20] for k, v in test.items()}
+    ts = test["Timestamp"][20:]
+    extra = np.concatenate([ts, db_obs["Timestamp"]])
+    hpv = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    ctx, dset = C.c_void_p(0), C.c_void_p(0)
+    _lib.call("magma_ctx_create", C.byref(ctx), 0)
+    N, info = C.c_int(0), C.c_int(0)
+    m0 = np.array([0.0])
+    _lib.call("magma_posterior_mu", ctx, C.byref(dset), ds.M, ds.M, 0, hpv(ds.off), hpv(ds.t), hpv(ds.y),
+              extra.size, hpv(np.ascontiguousarray(extra)), hpv(th0), hpv(np.ascontiguousarray(thi)), 3,
+              0.1, hpv(m0), C.byref(N), C.byref(info))
+    assert info.value == 0
+    grid = np.empty(N.value)
+    _lib.call("magma_dataset_grid", dset, hpv(grid))
+    mean, cov = np.empty(N.value), np.empty((N.value, N.value))
+    _lib.call("magma_get_mean", ctx, dset, hpv(mean))
+    _lib.call("magma_get_cov", ctx, dset, hpv(cov), N.value)
+    mu = orc.posterior_mu(train, db_obs, ts, 0.0, orc.kernel, orc.kernel, hp)
+    assert np.array_equal(grid, mu["cov"][0])
+    assert np.abs(cov - mu["cov"][1]).max() < 1e-9 * np.abs(mu["cov"][1]).max()
+    assert np.abs(mean - mu["mean"]["Output"]).max() < 1e-9
+    # pred_gp against the resident hyper-posterior
+    o = np.argsort(db_obs["Timestamp"], kind="stable")
+    tn, yn = np.ascontiguousarray(db_obs["Timestamp"][o]), np.ascontiguousarray(db_obs["Output"][o])
+    tss = np.ascontiguousarray(np.sort(ts))
+    off_n, off_t = np.array([0, tn.size], dtype=np.int64), np.array([0, tss.size], dtype=np.int64)
+    th = np.array([1.1, 0.6, 0.3])
+    pm, pv, pinfo = np.empty(tss.size), np.empty(tss.size), np.zeros(1, dtype=np.int32)
+    _lib.call("magma_pred_gp_resident", ctx, dset, 1, hpv(off_n), hpv(tn), hpv(yn), hpv(off_t), hpv(tss),
+              hpv(th), 0, hpv(pm), hpv(pv), hpv(pinfo))
+    exp = orc.pred_gp({"Timestamp": tn, "Output": yn}, tss, mu["mean"], mu["cov"], orc.kernel, th[:2], th[2])
+    assert pinfo[0] == 0
+    assert np.abs(pm - exp["Mean"]).max() < 1e-8 * np.abs(exp["Mean"]).max()
+    assert np.abs(pv - exp["Var"]).max() < 1e-8 * np.abs(exp["Var"]).max()
+    bad = np.array([0.123])
+    rc = _lib.load().magma_pred_gp_resident(ctx, dset, 1, hpv(off_n), hpv(tn), hpv(yn),
+                                            hpv(np.array([0, 1], dtype=np.int64)), hpv(bad), hpv(th), 0,
+                                            hpv(pm), hpv(pv), hpv(pinfo))
+    assert rc == 6 and b"subscript out of bounds" in _lib.load().magma_last_error()
+    _lib.load().magma_dataset_destroy(dset)
+    _lib.load().magma_ctx_destroy(ctx)
+    # train_new_gp natively == the Python-driven route of api.train_new_gp (same optimiser source)
+    mean_obs = orc._mean_at(mu["mean"], tn)
+    cov_obs = orc._block(mu["cov"][0], mu["cov"][1], tn)
+    got, status = train_new_gp(tn, yn, mean_obs, cov_obs, [1.0, 1.0, 0.2])
+    ref = m.train_new_gp({"Timestamp": tn, "Output": yn}, mu["mean"], mu["cov"], np.array([1.0, 1.0, 0.2]),
+                         m.kernel)
+    assert status in (1, 2, 3, 4)
+    assert np.abs(got - np.append(ref["theta"], ref["sigma"])).max() < 1e-12
