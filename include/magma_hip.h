@@ -12,9 +12,14 @@
  *    after magma_stream_sync(stream) (or any later work on the same stream).
  *  - Return value: 0 = ok, >0 = error; magma_last_error() gives the message (thread-local).
  *    A covariance that is not numerically positive definite is NOT an error: the per-matrix
- *    `info` output is non-zero (index of the first bad pivot, LAPACK dpotrf style) and that
- *    matrix's outputs are NaN / skipped; the host decides (the R code falls back to ginv,
- *    CF:133,161,387).
+ *    `info` output is non-zero (index of the first bad pivot, LAPACK dpotrf style). For the small
+ *    per-individual matrices of the E-step and of magma_kern_to_inv_batched such a matrix then
+ *    goes through the reference's `tryCatch(solve(.), error -> MASS::ginv(.))` (CF:133,161) on the
+ *    device: LU with partial pivoting, and the pseudo-inverse (symmetric Jacobi, MASS::ginv's
+ *    tolerance) when that is singular to machine precision -- parity with R unpinned, no
+ *    reference fixture reaches it. The M-step objective of such a matrix evaluates to NaN (a
+ *    failed trial point for the optimiser); the dense N x N objects report info and the host
+ *    decides.
  *  - Ragged dataset: individual i owns rows off[i]..off[i+1]-1 of t / y / idx (timestamps
  *    ascending within an individual, as the reference assumes: CF:74,95). idx[] is the int32
  *    position of each timestamp in the sorted union grid (replaces the `paste0('X', t)` names of

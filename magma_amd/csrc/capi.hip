@@ -226,8 +226,12 @@ int magma_kern_to_inv_batched(int M, int nmax, const int64_t* off, const int64_t
   if (int rc = check_small(M, nmax)) return rc;
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
   Prof pf(PROF_INV_BATCHED, S(stream));
-  return launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv_out, logdet_out,
-                               info_out, nullptr, nullptr, S(stream));
+  if (int rc = launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv_out, logdet_out,
+                                     info_out, nullptr, nullptr, S(stream)))
+    return rc;
+  // info != 0: tryCatch(solve(.), error -> MASS::ginv(.)) (CF:161) on the product side
+  return launch_small_slowpath(M, off, off2, t, nullptr, nullptr, theta, theta_stride, info_out,
+                               Kinv_out, nullptr, logdet_out, nullptr, 0, nullptr, nullptr, S(stream));
 }
 
 int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, const double* y,
@@ -236,8 +240,12 @@ int magma_estep_scatter(int M, int nmax, const int64_t* off, const double* t, co
   if (int rc = check_small(M, nmax)) return rc;
   if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
   Prof pf(PROF_SCATTER, S(stream));
-  return launch_estep_scatter(M, nmax, off, t, y, idx, theta, theta_stride, P, magma_pad(N), w,
-                              info_out, S(stream));
+  if (int rc = launch_estep_scatter(M, nmax, off, t, y, idx, theta, theta_stride, P, magma_pad(N), w,
+                                    info_out, S(stream)))
+    return rc;
+  // off2 is not needed when the answer goes straight into P / w
+  return launch_small_slowpath(M, off, off, t, y, idx, theta, theta_stride, info_out, nullptr, nullptr,
+                               nullptr, P, magma_pad(N), w, nullptr, S(stream));
 }
 
 int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2, const double* t,
@@ -254,6 +262,9 @@ int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2,
   int rc;
   if ((rc = launch_se_inv_batched(M, nmax, off, off2, t, theta, theta_stride, Kinv, logdet_scratch,
                                   info_out, y, v, st)))
+    return rc;
+  if ((rc = launch_small_slowpath(M, off, off2, t, y, nullptr, theta, theta_stride, info_out, Kinv, v,
+                                  logdet_scratch, nullptr, 0, nullptr, nullptr, st)))
     return rc;
   if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, 0, st))) return rc;
   return launch_csr_gather_sum(ntgt_w, ptr_w, src_w, tgt_w, v, w, 1, st);

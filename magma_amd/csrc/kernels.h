@@ -27,6 +27,11 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
 void set_resident_max_workgroups(int v);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
+// solve() / ginv() slow path for the individuals whose info != 0 (see small.hip)
+int launch_small_slowpath(int M, const int64_t* off, const int64_t* off2, const double* t,
+                          const double* y, const int* idx, const double* theta, int tstride,
+                          const int* info, double* Kinv, double* v, double* logdet, double* P,
+                          int64_t ldp, double* w, int* route, hipStream_t st);
 int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,
                           const double* val, double* out, int wave_per_target, hipStream_t st);
 // update_inv / update_mean on explicit K_i^-1 blocks (any n_i): P[idx_i, idx_i] += K_i^-1 (P != null)

@@ -211,8 +211,9 @@ __device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParam
 }
 
 // ------------------------------------------------------------------ K1+K3: inverse to HBM
-// With y / v given (the deterministic E-step): v_i = K_i^-1 y_i as well, and a flagged (not
-// positive definite) individual gets zeros in both, since it contributes nothing to the E-step.
+// With y / v given (the deterministic E-step): v_i = K_i^-1 y_i as well; a flagged (not positive
+// definite) individual gets zeros in both here and its solve() / ginv() answer from
+// small_slowpath_kernel, launched right behind this kernel.
 template <int NMAX>
 __global__ __launch_bounds__(64) void se_inv_batched_kernel(
     int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64) void estep_scatter_kernel(
   int info;
   se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
   if (lane == 0) info_out[i] = info;
-  if (info != 0) return;  // flagged: contributes nothing; the host reports it
+  if (info != 0) return;  // flagged: small_slowpath_kernel adds its solve() / ginv() answer
   if (rv) {  // lane r owns row r = column r of K^-1: Ks[c * NMAX + r] is conflict free
     double wi = 0.0;
 #pragma unroll
@@ -290,6 +291,251 @@ __global__ __launch_bounds__(64) void estep_scatter_kernel(
 #pragma unroll
     for (int c = 0; c < NMAX; ++c) {
       if (c <= lane) unsafeAtomicAdd(&P[(int64_t)ibuf[c] * ldp + ir], Ks[c * NMAX + lane]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ slow path: solve() / ginv()
+// `tryCatch(solve(mat), error = function(e) MASS::ginv(mat))` (CF:133,161; MG:173) for the K_i the
+// Cholesky-type sweep flagged (info != 0): numerically singular or indefinite by rounding
+// (sigma -> 0, near-duplicate timestamps, a huge length scale). One wavefront per flagged
+// matrix, everything in LDS, plain FP64 (a slow path: correctness over speed):
+//  1. solve(): Gauss-Jordan with partial pivoting on [K | I] (the pivoting of LAPACK dgesv, which
+//     R's solve() calls); R raises an error when a pivot is exactly zero or the reciprocal
+//     condition number is below .Machine$double.eps -- taken here as 1 / (|K|_1 |K^-1|_1) from
+//     the computed inverse (R: dgecon's estimate of the same quantity).
+//  2. ginv(): K is symmetric, so its SVD is its eigen-decomposition up to signs: cyclic Jacobi
+//     (round-robin pairs, two-sided rotations) to K = Q diag(lambda) Q', then
+//     ginv = sum over |lambda_k| > sqrt(eps) max|lambda| of q_k q_k' / lambda_k (MASS::ginv's
+//     tolerance on the singular values |lambda_k|).
+// Parity with R is UNPINNED for this path (no reference fixture reaches it).
+// Output: K_i^-1 (or the pseudo-inverse) into Kinv_out / v_out (gather route), or added into
+// P / w with atomics (P != null). logdet_out (optional): log|det K| of the LU, NaN after ginv().
+// route_out[i]: 1 = solve() answered, 2 = ginv().
+constexpr int SP_LD = 65;
+constexpr int SP_LDS_DOUBLES = 2 * 64 * SP_LD + 5 * 64;
+
+__global__ __launch_bounds__(64) void small_slowpath_kernel(
+    int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
+    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ theta, int tstride, const int* __restrict__ info,
+    double* __restrict__ Kinv_out, double* __restrict__ v_out, double* __restrict__ logdet_out,
+    double* __restrict__ P, int64_t ldp, double* __restrict__ w, int* __restrict__ route_out) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];
+  double* A = sp;                  // [64][SP_LD]
+  double* B = sp + 64 * SP_LD;     // [64][SP_LD]
+  double* tbuf = B + 64 * SP_LD;   // timestamps
+  double* cbuf = tbuf + 64;        // rotation cosines / row k of A
+  double* sbuf = cbuf + 64;        // rotation sines / row k of B
+  double* lam = sbuf + 64;         // eigenvalues
+  int* pq = reinterpret_cast<int*>(lam + 64);  // [64]: pairs of the current round (p, q)
+  const int lane = threadIdx.x;
+  const double eps = 2.220446049250313e-16;
+  for (int i = blockIdx.x; i < M; i += gridDim.x) {
+    if (info[i] == 0) continue;  // wave-uniform
+    const int64_t o = off[i];
+    const int n = (int)(off[i + 1] - o);
+    const double* th = theta + (int64_t)i * tstride;
+    const SEParams p = se_params(th[0], th[1], th[2]);
+    __syncthreads();
+    tbuf[lane] = lane < n ? t[o + lane] : 0.0;
+    __syncthreads();
+    auto build = [&]() {  // lane r builds row r of K into A; returns its column... (symmetric)
+      double colsum = 0.0;
+      if (lane < n)
+        for (int c = 0; c < n; ++c) {
+          const double d = tbuf[lane] - tbuf[c];
+          const double v = (c == lane) ? (p.eth1 + p.sig2) : exp(p.th1 - p.h * d * d);
+          A[lane * SP_LD + c] = v;
+          colsum += fabs(v);
+        }
+      return colsum;  // = 1-norm of column `lane` by symmetry
+    };
+    double n1 = build();
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) n1 = fmax(n1, __shfl_xor(n1, s));
+    if (lane < n)
+      for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
+    __syncthreads();
+    // ---- 1. solve(): Gauss-Jordan, partial pivoting
+    bool singular = false;
+    double logdet = 0.0;
+    for (int k = 0; k < n; ++k) {
+      double best = (lane >= k && lane < n) ? fabs(A[lane * SP_LD + k]) : -1.0;
+      int bi = lane;
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {
+        const double ob = __shfl_xor(best, s);
+        const int oi = __shfl_xor(bi, s);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (!(best > 0.0) || !(best < 1.7e308)) {
+        singular = true;
+        break;
+      }
+      if (lane < n && bi != k) {  // swap rows k and bi (lane = column)
+        const double a = A[k * SP_LD + lane], b = A[bi * SP_LD + lane];
+        A[k * SP_LD + lane] = b;
+        A[bi * SP_LD + lane] = a;
+        const double c = B[k * SP_LD + lane], d = B[bi * SP_LD + lane];
+        B[k * SP_LD + lane] = d;
+        B[bi * SP_LD + lane] = c;
+      }
+      __syncthreads();
+      const double piv = A[k * SP_LD + k];
+      logdet += log(fabs(piv));
+      if (lane < n) {
+        cbuf[lane] = A[k * SP_LD + lane] / piv;
+        sbuf[lane] = B[k * SP_LD + lane] / piv;
+      }
+      __syncthreads();
+      if (lane < n) {
+        if (lane == k) {
+          for (int c = 0; c < n; ++c) {
+            A[k * SP_LD + c] = cbuf[c];
+            B[k * SP_LD + c] = sbuf[c];
+          }
+        } else {
+          const double f = A[lane * SP_LD + k];
+          for (int c = 0; c < n; ++c) {
+            A[lane * SP_LD + c] = fma(-f, cbuf[c], A[lane * SP_LD + c]);
+            B[lane * SP_LD + c] = fma(-f, sbuf[c], B[lane * SP_LD + c]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    int route = 1;
+    if (!singular) {
+      double ni = 0.0;  // 1-norm of column `lane` of the computed inverse
+      bool fin = true;
+      if (lane < n)
+        for (int r = 0; r < n; ++r) {
+          const double v = B[r * SP_LD + lane];
+          ni += fabs(v);
+          fin = fin && ((v - v) == 0.0);
+        }
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) ni = fmax(ni, __shfl_xor(ni, s));
+      const bool allfin = __all(fin);
+      if (!allfin || !(1.0 / (n1 * ni) >= eps)) singular = true;
+    }
+    double* R = B;  // where the answer is
+    if (singular) {
+      // ---- 2. ginv(): Jacobi eigen-decomposition of K (A), eigenvectors in B
+      route = 2;
+      logdet = __longlong_as_double(0x7ff8000000000000LL);
+      __syncthreads();
+      (void)build();
+      if (lane < n)
+        for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
+      __syncthreads();
+      const int ne = n + (n & 1);  // even number of players; index n (if any) is a bye
+      const int half = ne / 2;
+      for (int sweep = 0; sweep < 40; ++sweep) {
+        double offd = 0.0, diag = 0.0;
+        if (lane < n)
+          for (int c = 0; c < n; ++c) {
+            const double v = A[lane * SP_LD + c];
+            if (c == lane) diag += v * v; else offd += v * v;
+          }
+        offd = wave_sum(offd);
+        diag = wave_sum(diag);
+        if (!(offd > 1e-30 * diag)) break;  // wave-uniform
+        for (int round = 0; round < ne - 1; ++round) {
+          // round-robin tournament: player ne-1 fixed, the others rotate
+          if (lane < half) {
+            int a = (lane == 0) ? ne - 1 : (round + lane) % (ne - 1);
+            int b = (round + ne - 1 - lane) % (ne - 1);
+            if (a > b) { const int x = a; a = b; b = x; }
+            double c = 1.0, sn = 0.0;
+            if (b < n) {
+              const double apq = A[a * SP_LD + b];
+              if (apq != 0.0) {
+                const double tau = (A[b * SP_LD + b] - A[a * SP_LD + a]) / (2.0 * apq);
+                const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                c = 1.0 / sqrt(1.0 + tt * tt);
+                sn = tt * c;
+              }
+            } else {
+              a = b = 0;  // bye: identity rotation on (0, 0), skipped below
+            }
+            pq[2 * lane] = a;
+            pq[2 * lane + 1] = b;
+            cbuf[lane] = c;
+            sbuf[lane] = sn;
+          }
+          __syncthreads();
+          if (lane < n) {  // columns: A <- A J, V <- V J (lane = row)
+            for (int k = 0; k < half; ++k) {
+              const int a = pq[2 * k], b = pq[2 * k + 1];
+              if (a == b) continue;
+              const double c = cbuf[k], sn = sbuf[k];
+              const double x = A[lane * SP_LD + a], z = A[lane * SP_LD + b];
+              A[lane * SP_LD + a] = c * x - sn * z;
+              A[lane * SP_LD + b] = sn * x + c * z;
+              const double u = B[lane * SP_LD + a], v = B[lane * SP_LD + b];
+              B[lane * SP_LD + a] = c * u - sn * v;
+              B[lane * SP_LD + b] = sn * u + c * v;
+            }
+          }
+          __syncthreads();
+          if (lane < n) {  // rows: A <- J' A (lane = column)
+            for (int k = 0; k < half; ++k) {
+              const int a = pq[2 * k], b = pq[2 * k + 1];
+              if (a == b) continue;
+              const double c = cbuf[k], sn = sbuf[k];
+              const double x = A[a * SP_LD + lane], z = A[b * SP_LD + lane];
+              A[a * SP_LD + lane] = c * x - sn * z;
+              A[b * SP_LD + lane] = sn * x + c * z;
+            }
+          }
+          __syncthreads();
+        }
+      }
+      double lk = lane < n ? A[lane * SP_LD + lane] : 0.0;
+      double lmax = fabs(lk);
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, s));
+      const double tol = 1.4901161193847656e-08 * lmax;  // sqrt(.Machine$double.eps) * d[1]
+      lam[lane] = (lane < n && fabs(lk) > tol) ? 1.0 / lk : 0.0;
+      __syncthreads();
+      if (lane < n)  // pseudo-inverse row `lane` into A (only its own row is overwritten)
+        for (int c = 0; c < n; ++c) {
+          double sacc = 0.0;
+          for (int k = 0; k < n; ++k) sacc = fma(B[lane * SP_LD + k] * lam[k], B[c * SP_LD + k], sacc);
+          A[lane * SP_LD + c] = sacc;
+        }
+      R = A;
+    }
+    __syncthreads();
+    // ---- output (R symmetric up to rounding: row `lane` read as column `lane`)
+    if (lane < n) {
+      double vi = 0.0;
+      if (y != nullptr)
+        for (int c = 0; c < n; ++c) vi = fma(R[lane * SP_LD + c], y[o + c], vi);
+      if (P != nullptr) {
+        const int ir = idx[o + lane];
+        unsafeAtomicAdd(&w[ir], vi);
+        for (int c = 0; c <= lane; ++c)
+          unsafeAtomicAdd(&P[(int64_t)idx[o + c] * ldp + ir], R[lane * SP_LD + c]);
+      } else {
+        if (v_out != nullptr) v_out[o + lane] = vi;
+        double* Ko = Kinv_out + off2[i];
+        // lower triangle from row `lane`, mirrored: the stored matrix is exactly symmetric
+        for (int c = 0; c <= lane; ++c) {
+          const double v = R[lane * SP_LD + c];
+          Ko[(int64_t)c * n + lane] = v;
+          Ko[(int64_t)lane * n + c] = v;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (logdet_out != nullptr) logdet_out[i] = logdet;
+      if (route_out != nullptr) route_out[i] = route;
     }
   }
 }
@@ -972,6 +1218,26 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "estep_scatter");
+}
+
+int launch_small_slowpath(int M, const int64_t* off, const int64_t* off2, const double* t,
+                          const double* y, const int* idx, const double* theta, int tstride,
+                          const int* info, double* Kinv, double* v, double* logdet, double* P,
+                          int64_t ldp, double* w, int* route, hipStream_t st) {
+  if (M <= 0) return 0;
+  const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (int rc = check_hip(hipFuncSetAttribute((const void*)small_slowpath_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                           "slow path LDS size"))
+      return rc;
+    attr_set = true;
+  }
+  const int grid = M < 512 ? M : 512;  // unflagged individuals cost one load each
+  hipLaunchKernelGGL(small_slowpath_kernel, dim3(grid), dim3(64), dyn, st, M, off, off2, t, y, idx,
+                     theta, tstride, info, Kinv, v, logdet, P, ldp, w, route);
+  return check_hip(hipGetLastError(), "small_slowpath");
 }
 
 int launch_csr_gather_sum(int64_t ntgt, const int64_t* ptr, const int* src, const int64_t* tgt,

@@ -47,6 +47,11 @@ def _solve_or_ginv(mat):
         inv = np.linalg.inv(mat)
         if not np.all(np.isfinite(inv)):
             raise np.linalg.LinAlgError("non-finite inverse")
+        # R: "system is computationally singular: reciprocal condition number = ..." when
+        # rcond < .Machine$double.eps (La_solve: dgecon's 1-norm estimate; here the 1-norm
+        # condition number of the computed inverse itself)
+        if 1.0 / (np.abs(mat).sum(axis=0).max() * np.abs(inv).sum(axis=0).max()) < np.finfo(float).eps:
+            raise np.linalg.LinAlgError("computationally singular")
         return inv
     except np.linalg.LinAlgError:
         return np.linalg.pinv(mat, rcond=np.sqrt(np.finfo(float).eps))
