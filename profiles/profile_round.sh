@@ -1,17 +1,29 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash profiles/profile_round.sh r01'): the bench line, the
-# rocprofv3 kernel trace of the same command and the two PMC passes behind roofline.traffic.
-# Outputs under gpurun_out/prof_<tag>/; copy the summaries into profiles/ afterwards.
-set -e
-tag=${1:-r01}
+# Run on the GPU box (gpurun -- 'bash profiles/profile_round.sh r02 20 5'): the bench line of the
+# DRIVER's command (--steps 20 --warmup 5 by default), the rocprofv3 kernel trace of the same
+# command, and separate PMC passes of the same command: FETCH_SIZE, WRITE_SIZE (roofline.traffic)
+# and the FP64 MFMA counters. Outputs under gpurun_out/prof_<tag>/; the summaries are copied into
+# profiles/ by hand afterwards (gpurun_out/ is scratch).
+tag=${1:-r02}
+steps=${2:-20}
+warm=${3:-5}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 python3 $root/bench.py --steps 3 --warmup 1 > $out/bench.json 2> $out/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.err
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.json 2> $out/pmc_fetch.err
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_write.json 2> $out/pmc_write.err
-python3 $root/profiles/pmc_summary.py $out/pmc_fetch_write.json FETCH_SIZE=$out/pmc_fetch WRITE_SIZE=$out/pmc_write
-find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+cmd="python3 $root/bench.py --steps $steps --warmup $warm"
+timeout -k 10 300 $cmd > $out/bench.json 2> $out/bench.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $cmd --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.err || exit 1
+rocprofv3 -L > $out/counters_available.txt 2>&1
+for pass in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  timeout -s KILL 240 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$name -o pmc -- $cmd --no-cpu-baseline > $out/pmc_$name.json 2> $out/pmc_$name.err || echo "pass $name failed" >> $out/failed.txt
+done
+python3 $root/profiles/pmc_summary.py $out/pmc_c3_${steps}_${warm}.json FETCH_SIZE=$out/pmc_FETCH_SIZE WRITE_SIZE=$out/pmc_WRITE_SIZE \
+  SQ_INSTS_VALU_MFMA_MOPS_F64=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 \
+  SQ_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64
+find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+# keep the merge small: the raw traces stay on the box
+find $out -name "*.csv" -size +1M -delete
+find $out -name "*.db" -delete
 ls $out
