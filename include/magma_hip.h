@@ -239,7 +239,11 @@ int magma_sum(int64_t n, const double* x, void* work, double* h_out, void* strea
  *    union grid of N points, uploaded once, with every buffer the EM needs (precision / cov,
  *    dense workspace, the gather lists of the deterministic E-step, packed cov blocks, optimiser
  *    outputs). Host arrays in: ragged off[M + 1] (off[0] = 0), t, y (timestamps strictly ascending
- *    within an individual, every one of them present in grid; n_i <= 64), grid ascending.
+ *    within an individual, every one of them present in grid), grid ascending. Individuals with
+ *    n_i <= 64 run on the one-wavefront-per-individual kernels; larger ones (any n_i <= N) take
+ *    the dense route inside the driver: K_i, its inverse and logL_GP_mod / gr_GP_mod through the
+ *    N x N kernels on the individual's own timestamps, one individual after the other (meant for
+ *    a few long series among many short ones, not for thousands of them).
  * Hyper-parameters are HOST arrays: theta_0 = 2 doubles; theta_i = (theta1, theta2, sigma) rows of
  * ALL M_total individuals (replicated on every rank; pen_diag averages over all of them, CF:381,
  * 409), or one triple with theta_stride 0. Calls are blocking; results in host memory. */

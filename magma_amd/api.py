@@ -130,6 +130,26 @@ def _batched_small(db, theta, sigma, inverse):
     import torch
     db = _as_db(db)
     ds = Dataset(db)
+    if ds.nmax > 64:
+        # individuals with more than 64 observations: the vector branch (dense kernels) each, the
+        # others batched (CF:85-112, 141-170 make no such distinction)
+        n = np.diff(ds.off)
+        res, small_rows = {}, []
+        for k, i in enumerate(ds.ids):
+            sl = slice(ds.off[k], ds.off[k + 1])
+            if n[k] > 64:
+                th = np.asarray(theta[i], float) if isinstance(theta, dict) else np.append(
+                    np.asarray(theta, float)[:2], sigma)
+                fn = kern_to_inv if inverse else kern_to_cov
+                res[i] = fn(ds.t[sl], kernel, th[:2], th[2])
+            else:
+                small_rows.append(np.arange(sl.start, sl.stop))
+        if small_rows:
+            rows = np.concatenate(small_rows)
+            sub = {"ID": np.repeat(np.array(ds.ids, dtype=object), n)[rows], "Timestamp": ds.t[rows],
+                   "Output": ds.y[rows]}
+            res.update(_batched_small(sub, theta, sigma, inverse))
+        return {i: res[i] for i in ds.ids}
     if isinstance(theta, dict):
         th = np.array([np.asarray(theta[i], float)[:3] for i in ds.ids])
         stride = 3

@@ -139,6 +139,49 @@ int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, do
   return 0;
 }
 
+int indiv_dense_eval_impl(int n, const double* grid, const double* th3, const double* yv,
+                          const double* mvec, const double* C, int want_grad, void* work,
+                          double* h_out4, int* h_info, hipStream_t st) {
+  if (n < 1) return fail(2, "n must be >= 1");
+  const int Np = ((n + 63) / 64) * 64;
+  const size_t n2 = (size_t)Np * Np;
+  Work wk(work, Np);
+  int rc;
+  if ((rc = launch_se_cov_grid(n, Np, grid, th3[0], th3[1], th3[2], wk.A0, st))) return rc;
+  if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
+  if ((rc = launch_theta0_vec(n, Np, wk.A0, C, yv, mvec, wk.alpha, wk.vpart, st))) return rc;
+  if (want_grad) {
+    if ((rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, C, Np, 0.0, wk.T, Np, st))) return rc;
+    if ((rc = launch_theta0_contract(n, Np, wk.T, wk.A0, wk.alpha, grid, th3[0], th3[1], wk.Z,
+                                     wk.partials, nullptr, st, nullptr)))
+      return rc;
+    // tr(W) = a'a + tr(K^-1 C K^-1) - tr(K^-1), tr(K^-1 C K^-1) = sum(T o K^-1) (both symmetric
+    // arguments; the identity padding adds one per padded row, taken off on the host). Z is
+    // free again after the contraction: scratch of the two dot products.
+    if ((rc = launch_dot(Np, wk.alpha, wk.alpha, wk.Z, wk.scal + 12, st))) return rc;
+    if ((rc = launch_dot((int64_t)n2, wk.T, wk.A0, wk.Z + 2048, wk.scal + 13, st))) return rc;
+    if ((rc = launch_trace(n, Np, wk.A0, wk.scal + 14, st))) return rc;
+  }
+  if ((rc = launch_theta0_finish2(n, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials, want_grad,
+                                  wk.scal + 8, st)))
+    return rc;
+  double h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h8, wk.scal + 8, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  const int info = (int)h8[3];
+  const double nanv = __builtin_nan("");
+  h_out4[0] = info ? nanv : h8[0];
+  h_out4[1] = info ? nanv : h8[1];
+  h_out4[2] = info ? nanv : h8[2];
+  h_out4[3] = 0.0;
+  if (want_grad) {
+    const double trW = h8[4] + (h8[5] - (double)(Np - n)) - h8[6];
+    h_out4[3] = info ? nanv : -th3[2] * trW;
+  }
+  if (h_info) *h_info = info;
+  return 0;
+}
+
 int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double pen_diag,
                       const double* mean, const double* m0, const double* cov, int m, double factr,
                       double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,

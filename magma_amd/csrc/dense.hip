@@ -800,6 +800,7 @@ __global__ void theta0_finish_kernel(int N, int Np, const double* __restrict__ s
   }
 }
 
+static int grid_for(int64_t n);
 // ------------------------------------------------------------------ driver helpers
 // (sum f, sum g0, sum g1, sum g2) over M individuals by one workgroup in a fixed order: the
 // common-HP objective (CF:203-234, 334-368) and the individual part of logL_monitoring.
@@ -843,6 +844,46 @@ __global__ __launch_bounds__(256) void pack_lower_kernel(int Np, double* __restr
     if (unpack) tile[m + (int64_t)n * Np] = buf[e];
     else buf[e] = tile[m + (int64_t)n * Np];
   }
+}
+
+// tr(A) over the true N x N part (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void trace_kernel(int N, int64_t ld, const double* __restrict__ A,
+                                                    double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int e = threadIdx.x; e < N; e += 256) s += A[(int64_t)e * (ld + 1)];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// One individual's view of the hyper-posterior for the dense evaluation route (n_i > 64):
+// C (np x np, identity padded) = cov[idx, idx], m (np, zero padded) = mean[idx].
+__global__ __launch_bounds__(256) void gather_block_kernel(int n, int np, const int* __restrict__ idx,
+                                                           const double* __restrict__ cov, int64_t ldc,
+                                                           const double* __restrict__ mean,
+                                                           double* __restrict__ C,
+                                                           double* __restrict__ m) {
+  const int64_t total = (int64_t)np * np;
+  for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e % np), c = (int)(e / np);
+    C[e] = (r < n && c < n) ? cov[(int64_t)idx[c] * ldc + idx[r]] : ((r == c) ? 1.0 : 0.0);
+  }
+  if (blockIdx.x == 0)
+    for (int e = threadIdx.x; e < np; e += 256) m[e] = e < n ? mean[idx[e]] : 0.0;
+}
+
+int launch_trace(int N, int64_t ld, const double* A, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, st, N, ld, A, out);
+  return check_hip(hipGetLastError(), "trace");
+}
+
+int launch_gather_block(int n, int np, const int* idx, const double* cov, int64_t ldc,
+                        const double* mean, double* C, double* m, hipStream_t st) {
+  hipLaunchKernelGGL(gather_block_kernel, dim3(grid_for((int64_t)np * np)), dim3(256), 0, st, n, np, idx,
+                     cov, ldc, mean, C, m);
+  return check_hip(hipGetLastError(), "gather_block");
 }
 
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st) {

@@ -26,6 +26,19 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
                       double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
                       const Theta0Shard* sh);
 
+// logL_GP_mod + gr_GP_mod (CF:181-201, 304-332) of ONE individual with more observations than a
+// wavefront handles (n > 64), on the dense kernels: the theta_0 evaluation chain on the
+// individual's own timestamps (grid: np values, ascending, zero padded) with three
+// hyper-parameters (sigma = th3[2], g3 = -sigma tr(W)). yv = outputs (np, zero padded), mvec =
+// mean process at the timestamps, C = cov block (np x np, identity padded; see
+// launch_gather_block). h_out4 = (f, g1, g2, g3); work: magma_workspace_bytes(n). Synchronises.
+int indiv_dense_eval_impl(int n, const double* grid, const double* th3, const double* yv,
+                          const double* mvec, const double* C, int want_grad, void* work,
+                          double* h_out4, int* h_info, hipStream_t st);
+int launch_trace(int N, int64_t ld, const double* A, double* out, hipStream_t st);
+int launch_gather_block(int n, int np, const int* idx, const double* cov, int64_t ldc,
+                        const double* mean, double* C, double* m, hipStream_t st);
+
 // out4 = (sum f, sum g[:,0], sum g[:,1], sum g[:,2]) over M entries, fixed order (g may be null)
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st);
 // lower 64 x 64 tiles of the Np x Np matrix P <-> contiguous buffer (tile (i, j <= i) at

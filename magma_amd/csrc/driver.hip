@@ -111,9 +111,25 @@ struct DevBuf {
 
 }  // namespace magma
 
+// An individual with more observations than one wavefront handles (n > 64): it takes the dense
+// route -- K_i, its inverse and its objective through the N x N kernels on its own timestamps.
+struct LargeIndiv {
+  int64_t row = 0;  // index among this rank's individuals
+  int n = 0, np = 0;
+  std::vector<double> h_t, h_y;
+  std::vector<int> h_idx;
+  DevBuf t, y, idx, off;  // t, y zero padded to np; off = {0, n}; (off2 = {0, 0}: `zero2`)
+};
+
 struct magma_dataset {
   magma_ctx* ctx = nullptr;
-  int64_t M = 0, M_total = 0, row0 = 0;
+  // M: the individuals the one-wavefront kernels handle (n <= 64), compact; Mloc: all of this
+  // rank's individuals; small_row[k]: index of small individual k among them
+  int64_t M = 0, Mloc = 0, M_total = 0, row0 = 0;
+  std::vector<int64_t> small_row;
+  std::vector<std::unique_ptr<LargeIndiv>> large;
+  int np_large = 0;
+  DevBuf LK, LKc, LC, Lm, Lwork, zero2, Lscal;
   int nmax = 1, N = 0, Np = 0;
   std::vector<int64_t> h_off, h_off2;
   std::vector<double> h_t, h_y, h_grid;
@@ -236,7 +252,30 @@ int sync(hipStream_t st) { return check_hip(hipStreamSynchronize(st), "stream sy
 int set_theta(magma_dataset* d, const double* h_theta_i, int stride, hipStream_t st) {
   if (stride == 0) return h2d(d->theta.p, h_theta_i, 3 * sizeof(double), st);
   if (d->M == 0) return 0;
-  return h2d(d->theta.p, h_theta_i + 3 * d->row0, (size_t)(3 * d->M) * sizeof(double), st);
+  if (d->large.empty())
+    return h2d(d->theta.p, h_theta_i + 3 * d->row0, (size_t)(3 * d->M) * sizeof(double), st);
+  std::vector<double> rows((size_t)(3 * d->M));
+  for (int64_t k = 0; k < d->M; ++k)
+    for (int q = 0; q < 3; ++q) rows[(size_t)(3 * k + q)] = h_theta_i[3 * (d->row0 + d->small_row[(size_t)k]) + q];
+  if (int rc = h2d(d->theta.p, rows.data(), rows.size() * sizeof(double), st)) return rc;
+  return sync(st);  // rows goes out of scope
+}
+
+// theta of local individual `row` (stride 0: the common triple)
+const double* theta_row(const magma_dataset* d, const double* h_theta_i, int stride, int64_t row) {
+  return stride == 0 ? h_theta_i : h_theta_i + 3 * (d->row0 + row);
+}
+
+// One large individual's f (and gradient) at th3 against the resident hyper-posterior.
+int large_eval(magma_ctx* c, magma_dataset* d, LargeIndiv& L, const double* th3, int want_grad,
+               double* out4, int* info) {
+  hipStream_t st = c->main;
+  if (int rc = launch_gather_block(L.n, L.np, L.idx.as<int>(), d->P.as<double>(), d->Np,
+                                   d->mean.as<double>(), d->LC.as<double>(), d->Lm.as<double>(), st))
+    return rc;
+  if (want_grad) d->stats.indiv_evals += 1;
+  return indiv_dense_eval_impl(L.n, L.t.as<double>(), th3, L.y.as<double>(), d->Lm.as<double>(),
+                               d->LC.as<double>(), want_grad, d->Lwork.p, out4, info, st);
 }
 
 int set_m0(magma_dataset* d, const double* h_m0, int n_m0, hipStream_t st) {
@@ -281,6 +320,19 @@ int sum_fi(magma_ctx* c, magma_dataset* d, const double* h_theta_i, int stride, 
     if (want_grad) d->stats.indiv_evals += d->M;
     if (int rc = launch_sum4(d->M, d->f.as<double>(), want_grad ? d->g.as<double>() : nullptr, fs, st))
       return rc;
+  }
+  if (!d->large.empty()) {  // dense route, one by one; added on the host, then back for the all-reduce
+    double loc[4];
+    if (int rc = d2h(loc, fs, 4 * sizeof(double), st)) return rc;
+    if (int rc = sync(st)) return rc;
+    for (auto& L : d->large) {
+      double o4[4];
+      int info = 0;
+      if (int rc = large_eval(c, d, *L, theta_row(d, h_theta_i, stride, L->row), want_grad, o4, &info)) return rc;
+      for (int q = 0; q < 4; ++q) loc[q] += o4[q];
+    }
+    if (int rc = h2d(fs, loc, 4 * sizeof(double), st)) return rc;
+    if (int rc = sync(st)) return rc;
   }
   if (int rc = c->allreduce(fs, 4, st)) return rc;
   if (int rc = d2h(out4, fs, 4 * sizeof(double), st)) return rc;
@@ -419,38 +471,55 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
   magma_dataset* d = new magma_dataset();
   std::unique_ptr<magma_dataset> guard(d);
   d->ctx = c;
-  d->M = M;
+  d->Mloc = M;
   d->M_total = M_total;
   d->row0 = row0;
   d->N = N;
   d->Np = magma_pad(N);
-  d->h_off.assign(1, 0);
-  if (M > 0) d->h_off.assign(h_off, h_off + M + 1);
-  if (d->h_off[0] != 0) return fail(2, "dataset: off[0] must be 0");
-  const int64_t R = d->h_off[(size_t)M];
-  d->h_t.assign(h_t, h_t + R);
-  d->h_y.assign(h_y, h_y + R);
+  if (M > 0 && h_off[0] != 0) return fail(2, "dataset: off[0] must be 0");
   d->h_grid.assign((size_t)d->Np, 0.0);
   std::copy(h_grid, h_grid + N, d->h_grid.begin());
-  d->h_idx.resize((size_t)R);
-  d->h_off2.assign((size_t)M + 1, 0);
+  d->h_off.assign(1, 0);
+  d->h_off2.assign(1, 0);
   d->nmax = 1;
+  int nmaxL = 0;
   for (int64_t i = 0; i < M; ++i) {
-    const int64_t o = d->h_off[(size_t)i], n = d->h_off[(size_t)i + 1] - o;
+    const int64_t o = h_off[i], n = h_off[i + 1] - o;
     if (n < 1) return fail(2, "dataset: every individual needs at least one observation");
-    if (n > MAGMA_NSMALL_MAX)
-      return fail(2, "dataset: an individual has more than 64 observations (one wavefront per individual)");
-    d->nmax = std::max(d->nmax, (int)n);
-    d->h_off2[(size_t)i + 1] = d->h_off2[(size_t)i] + n * n;
+    std::vector<int> ix((size_t)n);
     for (int64_t k = o; k < o + n; ++k) {
       if (k > o && !(h_t[k] > h_t[k - 1]))
         return fail(2, "dataset: timestamps must be strictly ascending within an individual");
       // exact match on the grid: replaces the reference's `paste0('X', t)` names (CF:78,451)
       const double* p = std::lower_bound(h_grid, h_grid + N, h_t[k]);
       if (p == h_grid + N || *p != h_t[k]) return fail(2, "dataset: a timestamp is not on the grid");
-      d->h_idx[(size_t)k] = (int)(p - h_grid);
+      ix[(size_t)(k - o)] = (int)(p - h_grid);
+    }
+    if (n <= MAGMA_NSMALL_MAX) {  // one wavefront per individual
+      d->small_row.push_back(i);
+      d->nmax = std::max(d->nmax, (int)n);
+      d->h_t.insert(d->h_t.end(), h_t + o, h_t + o + n);
+      d->h_y.insert(d->h_y.end(), h_y + o, h_y + o + n);
+      d->h_idx.insert(d->h_idx.end(), ix.begin(), ix.end());
+      d->h_off.push_back(d->h_off.back() + n);
+      d->h_off2.push_back(d->h_off2.back() + n * n);
+    } else {  // the dense route
+      std::unique_ptr<LargeIndiv> L(new LargeIndiv());
+      L->row = i;
+      L->n = (int)n;
+      L->np = magma_pad((int)n);
+      L->h_t.assign((size_t)L->np, 0.0);
+      L->h_y.assign((size_t)L->np, 0.0);
+      std::copy(h_t + o, h_t + o + n, L->h_t.begin());
+      std::copy(h_y + o, h_y + o + n, L->h_y.begin());
+      L->h_idx = ix;
+      nmaxL = std::max(nmaxL, (int)n);
+      d->large.push_back(std::move(L));
     }
   }
+  d->M = (int64_t)d->small_row.size();
+  M = d->M;  // from here on: the compact set of small individuals
+  const int64_t R = d->h_off[(size_t)M];
   int rc;
   if ((rc = upload(d->off, d->h_off)) || (rc = upload(d->off2, d->h_off2)) || (rc = upload(d->t, d->h_t)) ||
       (rc = upload(d->y, d->h_y)) || (rc = upload(d->idx, d->h_idx)) || (rc = upload(d->grid, d->h_grid)))
@@ -485,6 +554,22 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
     d->nplist = (int)pl.size();
     if ((rc = upload(d->plist, pl))) return rc;
   }
+  if (!d->large.empty()) {
+    d->np_large = magma_pad(nmaxL);
+    const size_t npl = (size_t)d->np_large;
+    const std::vector<int64_t> z2 = {0, 0};
+    if ((rc = d->LK.alloc(sizeof(double) * npl * npl)) || (rc = d->LKc.alloc(sizeof(double) * npl * npl)) ||
+        (rc = d->LC.alloc(sizeof(double) * npl * npl)) || (rc = d->Lm.alloc(sizeof(double) * npl)) ||
+        (rc = d->Lwork.alloc(magma_workspace_bytes(nmaxL))) || (rc = d->Lscal.alloc(sizeof(double) * 8)) ||
+        (rc = upload(d->zero2, z2)))
+      return rc;
+    for (auto& L : d->large) {
+      const std::vector<int64_t> offL = {0, (int64_t)L->n};
+      if ((rc = upload(L->t, L->h_t)) || (rc = upload(L->y, L->h_y)) || (rc = upload(L->idx, L->h_idx)) ||
+          (rc = upload(L->off, offL)))
+        return rc;
+    }
+  }
   MAGMA_CHECK_HIP(hipMemset(d->mean.p, 0, sizeof(double) * Np));
   MAGMA_CHECK_HIP(hipMemset(d->m0.p, 0, sizeof(double) * Np));
   *out = guard.release();
@@ -499,8 +584,11 @@ void magma_dataset_destroy(magma_dataset* d) {
 
 int magma_dataset_info(const magma_dataset* d, int64_t* M, int* nmax, int* N, int* Np) {
   if (!d) return fail(2, "dataset is NULL");
-  if (M) *M = d->M;
-  if (nmax) *nmax = d->nmax;
+  if (M) *M = d->Mloc;
+  if (nmax) {
+    *nmax = d->nmax;
+    for (auto& L : d->large) *nmax = std::max(*nmax, L->n);
+  }
   if (N) *N = d->N;
   if (Np) *Np = d->Np;
   return 0;
@@ -578,6 +666,27 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                d->ptrw.as<int64_t>(), d->srcw.as<int>(), d->tgtw.as<int64_t>(),
                                d->P.as<double>(), d->w.as<double>(), d->info.as<int>(), st)))
     return rc;
+  for (auto& L : d->large) {
+    // n_i > 64: K_i and its inverse on the dense kernels (kern_to_inv, CF:141-170), then
+    // update_inv / update_mean (CF:440-478) on that explicit block
+    const double* th = theta_row(d, h_theta_i, theta_stride, L->row);
+    double* sc = d->Lscal.as<double>();
+    int* li = reinterpret_cast<int*>(sc + 2);
+    if ((rc = magma_kern_to_cov_grid(L->n, L->t.as<double>(), th[0], th[1], th[2], d->LK.as<double>(), st)) ||
+        (rc = magma_spd_inverse(L->n, d->LK.as<double>(), sc, li, d->Lwork.p, st)))
+      return rc;
+    int linfo = 0;
+    if ((rc = d2h(&linfo, li, sizeof(int), st)) || (rc = sync(st))) return rc;
+    if (linfo != 0) {  // (the solve() / ginv() slow path covers n_i <= 64 only: left out, counted)
+      d->stats.flagged += 1;
+      continue;
+    }
+    if ((rc = magma_copy_unpad(L->n, d->LK.as<double>(), d->LKc.as<double>(), L->n, st)) ||
+        (rc = launch_update_inv(1, L->off.as<int64_t>(), d->zero2.as<int64_t>(), L->idx.as<int>(),
+                                d->LKc.as<double>(), L->y.as<double>(), d->P.as<double>(), d->Np,
+                                d->w.as<double>(), st)))
+      return rc;
+  }
   if (c->has_comm()) {
     // partial precision sums: only the lower tiles carry anything -- packed, summed, unpacked
     const int nt = d->Np / 64;
@@ -751,12 +860,41 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
         d->stats.indiv_rounds += mx;
       } while (false);
     }
+    // results by local row; individuals on the dense route are optimised one after the other by
+    // the host-side L-BFGS-B around the dense evaluation (CF:423-431 for n_i > 64)
+    std::vector<double> loc((size_t)(3 * std::max<int64_t>(d->Mloc, 1)));
+    for (int64_t k = 0; k < M; ++k)
+      for (int q = 0; q < 3; ++q) loc[(size_t)(3 * d->small_row[(size_t)k] + q)] = hx[(size_t)(3 * k + q)];
+    for (auto& L : d->large) {
+      if (rc) break;
+      const double* start = theta_row(d, h_theta_i, 3, L->row);
+      magma_lbfgsb* lb = magma_lbfgsb_create(1, 3, start, o.m, o.factr, o.pgtol, o.maxit);
+      if (!lb) {
+        rc = fail(2, "m_step: bad optimiser parameters");
+        break;
+      }
+      bool first = true;
+      while (!rc) {
+        double x[3], o4[4];
+        unsigned char act = 0;
+        int na = 0, info = 0;
+        if ((rc = magma_lbfgsb_ask(lb, x, &act, &na)) || na == 0) break;
+        if ((rc = large_eval(c, d, *L, x, 1, o4, &info))) break;
+        if (first) sums[0] += o4[0];
+        first = false;
+        if ((rc = magma_lbfgsb_tell(lb, o4, o4 + 1))) break;
+      }
+      double fb = 0.0;
+      if (!rc) rc = magma_lbfgsb_result(lb, &loc[(size_t)(3 * L->row)], &fb, nullptr, nullptr, nullptr);
+      magma_lbfgsb_destroy(lb);
+      sums[1] += fb;
+    }
     // the theta_0 thread may still be using the communicator: wait for it before this thread does
     if (int r2 = join0()) rc = rc ? rc : r2;
     if (!rc && c->has_comm()) {
       double* gb = d->gath.as<double>();
       rc = check_hip(hipMemsetAsync(gb, 0, sizeof(double) * 3 * (size_t)Mt, st), "m_step gather");
-      if (!rc && M > 0) rc = h2d(gb + 3 * d->row0, hx.data(), sizeof(double) * 3 * (size_t)M, st);
+      if (!rc && d->Mloc > 0) rc = h2d(gb + 3 * d->row0, loc.data(), sizeof(double) * 3 * (size_t)d->Mloc, st);
       if (!rc) rc = c->allreduce(gb, 3 * Mt, st);
       if (!rc) rc = d2h(h_theta_i_out, gb, sizeof(double) * 3 * (size_t)Mt, st);
       double* fs = d->fsum.as<double>();
@@ -765,7 +903,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
       if (!rc) rc = d2h(sums, fs, 2 * sizeof(double), st);
       if (!rc) rc = sync(st);
     } else if (!rc) {
-      std::copy(hx.begin(), hx.begin() + 3 * M, h_theta_i_out);
+      std::copy(loc.begin(), loc.begin() + 3 * d->Mloc, h_theta_i_out);
     }
   }
   if (int r2 = join0()) rc = rc ? rc : r2;

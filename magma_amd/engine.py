@@ -57,10 +57,9 @@ class Dataset:
         self.grid = np.unique(np.concatenate(pieces))
         self.N = int(self.grid.size)
         self.idx = np.searchsorted(self.grid, self.t).astype(np.int32)
+        # (individuals with more than 64 observations take the dense route of the native driver,
+        # magma_amd.native; the kernel-level HipBackend handles one wavefront per individual)
         self.nmax = int(counts.max()) if counts.size else 1
-        if self.nmax > N_SMALL_MAX:
-            raise ValueError(f"an individual has {self.nmax} observations; the HIP path handles "
-                             f"n_i <= {N_SMALL_MAX} (one wavefront per individual)")
         dup = (np.diff(self.t) <= 0) & (g_sorted[1:] == g_sorted[:-1])
         if np.any(dup):
             bad = self.ids[int(g_sorted[1:][dup][0])]
@@ -79,8 +78,6 @@ class Dataset:
         self.N = int(self.grid.size)
         self.idx = np.searchsorted(self.grid, self.t).astype(np.int32)
         self.nmax = int(np.diff(self.off).max()) if self.M else 1
-        if self.nmax > N_SMALL_MAX:
-            raise ValueError("n_i <= 64 required")
         return self
 
     def shard(self, rank, world):
@@ -104,6 +101,11 @@ class HipBackend:
         if not torch.cuda.is_available():
             raise _lib.MagmaHipError("no GPU visible: the HIP path has no CPU fallback")
         self.lib = _lib.load()
+        if ds.nmax > N_SMALL_MAX:
+            raise ValueError(f"an individual has {ds.nmax} observations; the kernel-level backend "
+                             f"handles n_i <= {N_SMALL_MAX} (one wavefront per individual): use "
+                             "magma_amd.native.NativeEngine, whose driver sends larger individuals "
+                             "down the dense route")
         self.dev = torch.device(device if device is not None else "cuda")
         if self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())

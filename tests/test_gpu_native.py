@@ -324,3 +324,56 @@ def test_native_posterior_mu_pred_gp_and_train_new_gp(m):
                          m.kernel)
     assert status in (1, 2, 3, 4)
     assert np.abs(got - np.append(ref["theta"], ref["sigma"])).max() < 1e-12
+
+
+# ------------------------------------------------------------------ n_i > 64
+def test_individuals_with_more_than_64_observations(m):
+    """kern_to_cov / kern_to_inv accept any length (CF:66-81, 95-104). Individuals with n_i > 64
+    take the dense route of the native driver (K_i, its inverse and logL_GP_mod / gr_GP_mod on the
+    N x N kernels, scattered with update_inv / update_mean): E-step, M-step objective sums and a
+    whole EM iteration against the oracle, in a db that mixes them with small individuals."""
+    from magma_amd.native import NativeEngine
+    rng = np.random.default_rng(65)
+    db = _ragged_db(rng, [30, 65, 12, 128, 40, 64, 100])
+    ds = m.Dataset(db)
+    assert ds.nmax == 128
+    th0 = np.array([0.9, 0.7])
+    thi = np.tile([1.0, 1.0, 0.4], (ds.M, 1)) + rng.uniform(-0.3, 0.3, size=(ds.M, 3))
+    hp = {"theta_0": th0, "theta_i": {i: thi[k] for k, i in enumerate(ds.ids)}}
+    pen = float(np.mean(thi[:, 2]))
+    nat = NativeEngine(ds)
+    assert nat.e_step(th0, thi, pen, 0.4) == 0
+    exp = orc.e_step(db, 0.4, orc.kernel, orc.kernel, hp)
+    sc = np.abs(exp["cov"][1]).max()
+    assert np.abs(nat.get_cov() - exp["cov"][1]).max() < 1e-9 * sc
+    assert np.abs(nat.get_mean() - exp["mean"]["Output"]).max() < 1e-9 * np.abs(exp["mean"]["Output"]).max()
+    ll = orc.logL_monitoring(hp, db, orc.kernel, orc.kernel, exp["mean"], exp["cov"], 0.4)
+    assert abs(nat.logL_monitoring(th0, thi) - ll) < 1e-10 * abs(ll)
+    # M-step: every individual's optimum against the oracle's m_step driven by the same optimiser
+    n0, ni = nat.m_step(th0, thi, False)
+
+    def same_opt(par, fn, gr):
+        r = m.minimize_batch(np.asarray(par, float)[None, :],
+                             lambda x, act: (np.array([fn(x[0])]), np.array([gr(x[0])])))
+        return r["x"][0]
+    new = orc.m_step(db, hp, exp["mean"], exp["cov"], orc.kernel, orc.kernel, 0.4, False, optimizer=same_opt)
+    ref = np.array([new["theta_i"][i] for i in ds.ids])
+    assert np.abs(n0 - new["theta_0"]).max() < 1e-6
+    assert np.abs(ni - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), np.abs(ni - ref).max(axis=1)
+    # the gradient of the dense route, through the common-HP objective (sum over all individuals)
+    a = nat.em_iteration(th0, np.tile([1.0, 1.0, 0.4], (ds.M, 1)), 0.4, True)
+    hp_c = {"theta_0": th0, "theta_i": {i: np.array([1.0, 1.0, 0.4]) for i in ds.ids}}
+    exp_c = orc.e_step(db, 0.4, orc.kernel, orc.kernel, hp_c)
+    new_c = orc.m_step(db, hp_c, exp_c["mean"], exp_c["cov"], orc.kernel, orc.kernel, 0.4, True,
+                       optimizer=same_opt)
+    assert np.abs(a[1][0] - new_c["theta_i"][ds.ids[0]]).max() < 1e-6
+    ll_c = orc.logL_monitoring(hp_c, db, orc.kernel, orc.kernel, exp_c["mean"], exp_c["cov"], 0.4)
+    assert abs(a[2] - ll_c) < 1e-9 * abs(ll_c)
+    nat.close()
+    # the R-named builders on the same db
+    got = m.kern_to_inv(db, m.kernel, hp["theta_i"], 0)
+    ref_inv = orc.kern_to_inv(db, orc.kernel, hp["theta_i"], 0)
+    for i in ds.ids:
+        assert np.abs(got[i][1] - ref_inv[i][1]).max() < 1e-9 * np.abs(ref_inv[i][1]).max(), i
+    with pytest.raises(ValueError, match="NativeEngine"):
+        m.Engine(ds)
