@@ -281,6 +281,9 @@ int magma_get_cov(magma_ctx* ctx, magma_dataset* ds, double* h_cov /* N x N, ld 
 /* load a hyper-posterior computed elsewhere (m_step / logL_* called on their own) */
 int magma_set_mean_cov(magma_ctx* ctx, magma_dataset* ds, const double* h_mean, const double* h_cov,
                        int64_t ld);
+/* the prior mean m_0 (n_m0 = 1: scalar, or N values) for m_step / logL_monitoring called on a
+ * hyper-posterior loaded with magma_set_mean_cov (magma_e_step sets it itself) */
+int magma_set_m0(magma_ctx* ctx, magma_dataset* ds, const double* h_m0, int n_m0);
 int magma_get_stats(const magma_dataset* ds, magma_em_stats* h_out, int reset);
 
 /* e_step (CF:371-395) on the dataset's grid with pen_diag given (CF:381: mean sigma_i; posterior_mu

@@ -87,6 +87,7 @@ SIGNATURES = {
     "magma_get_mean": (_i, [_p, _p, _p]),
     "magma_get_cov": (_i, [_p, _p, _p, _i64]),
     "magma_set_mean_cov": (_i, [_p, _p, _p, _p, _i64]),
+    "magma_set_m0": (_i, [_p, _p, _p, _i]),
     "magma_get_stats": (_i, [_p, _p, _i]),
     "magma_e_step": (_i, [_p, _p, _p, _p, _i, _d, _p, _i, C.POINTER(_i), C.POINTER(_d)]),
     "magma_m_step": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),

@@ -636,6 +636,12 @@ int magma_set_mean_cov(magma_ctx* c, magma_dataset* d, const double* h_mean, con
   return sync(st);
 }
 
+int magma_set_m0(magma_ctx* c, magma_dataset* d, const double* h_m0, int n_m0) {
+  if (!c || !d || !h_m0) return fail(2, "set_m0: NULL argument");
+  if (int rc = set_device(c)) return rc;
+  return set_m0(d, h_m0, n_m0, c->main);
+}
+
 int magma_get_stats(const magma_dataset* d, magma_em_stats* out, int reset) {
   if (!d || !out) return fail(2, "get_stats: NULL argument");
   *out = d->stats;

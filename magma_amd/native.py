@@ -205,6 +205,10 @@ class NativeEngine:
         mean, cov = _f64(mean), _f64(cov)
         _lib.call("magma_set_mean_cov", self._ctx, self._ds, _hp(mean), _hp(cov), cov.shape[0])
 
+    def set_m0(self, m0):
+        mv, nm = self._m0(m0)
+        _lib.call("magma_set_m0", self._ctx, self._ds, _hp(mv), nm)
+
     def get_mean(self):
         out = np.empty(self.N)
         _lib.call("magma_get_mean", self._ctx, self._ds, _hp(out))

@@ -11,7 +11,24 @@
 ## Only the SE kernel (`kernel` / `kernel_mu`) is accelerated; any other kernel falls back to
 ## the reference's R code, kept under the names *_ref.
 
+## The native driver (one .Call per reference function) is used for `training`, `m_step`,
+## `train_new_gp`; set options(magmahip.native = FALSE) to keep R's loops over the per-evaluation
+## calls (e.g. to let `opm` use another optimiser).
 dyn.load(file.path(Sys.getenv("MAGMAHIP_DIR", "."), "magmahip.so"))
+.hip_native <- function() isTRUE(getOption("magmahip.native", TRUE))
+
+## db -> native dataset handle (rows of an individual contiguous, Timestamp ascending)
+.hip_dataset <- function(db, extra_t = NULL) {
+  db$ID <- as.character(db$ID)
+  ids <- unique(db$ID)
+  rows <- lapply(ids, function(i) { d <- db[db$ID == i, ]; d[order(d$Timestamp), ] })
+  n <- vapply(rows, nrow, 1L)
+  t <- unlist(lapply(rows, function(d) d$Timestamp))
+  y <- unlist(lapply(rows, function(d) d$Output))
+  grid <- sort(unique(c(t, extra_t)))
+  list(ptr = .Call("magmahip_dataset", as.integer(c(0L, cumsum(n))), as.double(t), as.double(y),
+                   as.double(grid)), ids = ids, grid = grid, off = as.integer(c(0L, cumsum(n))), t = t, y = y)
+}
 
 .hip_is_se <- function(k) identical(k, kernel) || identical(k, kernel_mu)
 
@@ -123,8 +140,19 @@ logL_monitoring <- function(hp, db, kern_i, kern_0, mean_mu, cov_mu, m_0) {
 ## kernels keep the reference's body.
 m_step_ref <- m_step
 m_step <- function(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp) {
-  if (common_hp || !(.hip_is_se(kern_0) && .hip_is_se(kern_i)))
+  if (!(.hip_is_se(kern_0) && .hip_is_se(kern_i)))
     return(m_step_ref(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp))
+  if (.hip_native()) {   # both branches in ONE call: magma_m_step
+    s <- .hip_dataset(db, mean$Timestamp)
+    th <- .hip_theta_mat(old_hp$theta_i, s$ids)
+    r <- .Call("magmahip_m_step", s$ptr, mean$Output[order(mean$Timestamp)], cov, as.double(m_0),
+               as.numeric(unlist(old_hp$theta_0))[1:2], th, common_hp)
+    if (anyNA(r[[1]]) || anyNA(r[[2]])) return(m_step_ref(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp))
+    new_theta_i <- lapply(seq_along(s$ids), function(j) setNames(r[[2]][, j], names(old_hp$theta_i[[1]])))
+    names(new_theta_i) <- s$ids
+    return(list(theta_0 = setNames(r[[1]], names(old_hp$theta_0)), theta_i = new_theta_i))
+  }
+  if (common_hp) return(m_step_ref(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp))
   s <- .hip_get(db, mean$Timestamp)
   th <- .hip_theta_mat(old_hp$theta_i, s$ids)
   pen_diag <- mean(2 * th[3, ])                                              # CF:409
@@ -137,4 +165,38 @@ m_step <- function(db, old_hp, mean, cov, kern_0, kern_i, m_0, common_hp) {
   new_theta_i <- lapply(seq_along(s$ids), function(j) setNames(r[[1]][, j], names(old_hp$theta_i[[1]])))
   names(new_theta_i) <- s$ids
   list(theta_0 = new_theta_0, theta_i = new_theta_i)
+}
+
+## training (MAGMA.R:15-82) as ONE .Call: the EM loop, both optimisers, the monitoring and the
+## stopping rule run inside the library (magma_training). Same return value as the reference.
+training_ref <- training
+training <- function(db, prior_mean, ini_hp, kern_0, kern_i, common_hp = T) {
+  if (!.hip_native() || !(.hip_is_se(kern_0) && .hip_is_se(kern_i)))
+    return(training_ref(db, prior_mean, ini_hp, kern_0, kern_i, common_hp))
+  t1 <- Sys.time()
+  s <- .hip_dataset(db)
+  r <- .Call("magmahip_training", s$ptr, as.double(prior_mean), as.numeric(unlist(ini_hp$theta_0))[1:2],
+             as.numeric(unlist(ini_hp$theta_i))[1:3], common_hp)
+  theta_i <- lapply(seq_along(s$ids), function(j) r[[2]][, j])
+  names(theta_i) <- s$ids
+  nm <- paste0("X", s$grid)
+  cov <- r[[7]]; dimnames(cov) <- list(nm, nm)
+  param <- list(mean = tibble::tibble(Timestamp = s$grid, Output = r[[6]]), cov = cov,
+                pred_GP = tibble::tibble(Timestamp = s$grid, Mean = r[[6]], Var = diag(cov)))
+  list(hp = list(theta_0 = r[[1]], theta_i = theta_i), convergence = r[[3]], param = param,
+       Time_train = Sys.time() - t1, plot = list(), logLL_trace = r[[5]][, seq_len(r[[4]]), drop = FALSE])
+}
+
+## train_new_gp (MAGMA.R:84-104): the 3-parameter L-BFGS-B inside the library (n <= 64)
+train_new_gp_ref <- train_new_gp
+train_new_gp <- function(db, mean_mu, cov_mu, ini_hp_i, kern_i) {
+  if (!.hip_native() || !.hip_is_se(kern_i) || nrow(db) > 64 || is.null(dim(cov_mu)))
+    return(train_new_gp_ref(db, mean_mu, cov_mu, ini_hp_i, kern_i))
+  db <- db[order(db$Timestamp), ]
+  mean <- if (is.vector(mean_mu)) rep(mean_mu, length.out = nrow(db)) else
+    mean_mu$Output[match(db$Timestamp, mean_mu$Timestamp)]
+  nm <- paste0("X", db$Timestamp)
+  r <- .Call("magmahip_train_new_gp", as.double(db$Timestamp), as.double(db$Output), as.double(mean),
+             cov_mu[nm, nm], as.numeric(unlist(ini_hp_i))[1:3])
+  list(theta = r[1:2], sigma = r[3])
 }

@@ -5,6 +5,10 @@
  * and load it from the sourced scripts with dyn.load("magmahip.so") (the reference is
  * script based: MAGMA.R:12 sources Computing_functions.R).
  *
+ * Two layers: the per-kernel "session" calls below (what `opm` drives per evaluation), and the
+ * native-driver calls at the end (magmahip_training, magmahip_m_step, ...: ONE .Call per reference
+ * function, the EM loop, the optimisers and the theta_0 side stream inside the library).
+ *
  * Conventions: inputs are read-only REAL()/INTEGER() views; outputs are freshly allocated,
  * column-major; a "session" external pointer owns the device copy of one db (ragged layout +
  * union grid + dense workspace) and is released by a finalizer. C ABI status codes become
@@ -242,7 +246,187 @@ SEXP magmahip_theta0_eval(SEXP sx, SEXP theta0, SEXP pen, SEXP m0, SEXP want_gra
   return out;
 }
 
+/* ---- the native driver: ONE .Call per reference function (magma_ctx / magma_dataset) ---- */
+typedef struct {
+  magma_ctx *ctx;
+  magma_dataset *ds;
+  int M, N;
+} native;
+
+static void native_free(native *h) {
+  if (!h) return;
+  if (h->ds) magma_dataset_destroy(h->ds);
+  if (h->ctx) magma_ctx_destroy(h->ctx);
+  free(h);
+}
+
+static void native_finalizer(SEXP x) {
+  native_free((native *)R_ExternalPtrAddr(x));
+  R_ClearExternalPtr(x);
+}
+
+static native *get_native(SEXP x) {
+  native *h = (native *)R_ExternalPtrAddr(x);
+  if (!h) Rf_error("magmahip: dataset already released");
+  return h;
+}
+
+/* off: integer M+1 (0-based), t / y: double (rows of an individual contiguous, Timestamp
+ * ascending), grid: double N (sorted unique). R is single-process: one context on device 0. */
+SEXP magmahip_dataset(SEXP off, SEXP t, SEXP y, SEXP grid) {
+  native *h = (native *)calloc(1, sizeof(native));
+  if (!h) Rf_error("magmahip: out of memory");
+  h->M = LENGTH(off) - 1;
+  h->N = LENGTH(grid);
+  int64_t *off64 = (int64_t *)malloc(sizeof(int64_t) * (h->M + 1));
+  int rc = off64 ? 0 : 1;
+  if (!rc) {
+    for (int i = 0; i <= h->M; ++i) off64[i] = INTEGER(off)[i];
+    rc = magma_ctx_create(&h->ctx, 0);
+    if (!rc)
+      rc = magma_dataset_create(h->ctx, &h->ds, h->M, h->M, 0, off64, REAL(t), REAL(y), h->N, REAL(grid));
+  }
+  free(off64);
+  if (rc) {
+    native_free(h);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP ptr = PROTECT(R_MakeExternalPtr(h, R_NilValue, R_NilValue));
+  R_RegisterCFinalizerEx(ptr, native_finalizer, TRUE);
+  UNPROTECT(1);
+  return ptr;
+}
+
+static SEXP native_param(native *h) { /* list(mean N, cov N x N) of the resident hyper-posterior */
+  SEXP mean = PROTECT(allocVector(REALSXP, h->N));
+  SEXP cov = PROTECT(allocMatrix(REALSXP, h->N, h->N));
+  int rc = magma_get_mean(h->ctx, h->ds, REAL(mean));
+  if (!rc) rc = magma_get_cov(h->ctx, h->ds, REAL(cov), h->N);
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(out, 0, mean);
+  SET_VECTOR_ELT(out, 1, cov);
+  UNPROTECT(3);
+  return out;
+}
+
+/* training (MG:15-82) as one call: list(theta_0 (2), theta_i (3 x M), convergence, iterations,
+ * trace (3 x n_loop_max: logLL(hp), logLL(new hp), eps per iteration), mean, cov). */
+SEXP magmahip_training(SEXP hx, SEXP m0, SEXP ini_theta0, SEXP ini_theta_i, SEXP common_hp) {
+  native *h = get_native(hx);
+  const int nloop = 25; /* MG:23 */
+  SEXP th0 = PROTECT(allocVector(REALSXP, 2));
+  SEXP thi = PROTECT(allocMatrix(REALSXP, 3, h->M));
+  SEXP trace = PROTECT(allocMatrix(REALSXP, 3, nloop));
+  for (int k = 0; k < 3 * nloop; ++k) REAL(trace)[k] = NA_REAL;
+  int cv = 0, its = 0;
+  int rc = magma_training(h->ctx, h->ds, REAL(m0), LENGTH(m0), REAL(ini_theta0), REAL(ini_theta_i),
+                          asLogical(common_hp), nloop, NULL, REAL(th0), REAL(thi), &cv, &its, REAL(trace));
+  if (rc) {
+    UNPROTECT(3);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP par = PROTECT(native_param(h));
+  SEXP out = PROTECT(allocVector(VECSXP, 7));
+  SET_VECTOR_ELT(out, 0, th0);
+  SET_VECTOR_ELT(out, 1, thi);
+  SET_VECTOR_ELT(out, 2, ScalarLogical(cv));
+  SET_VECTOR_ELT(out, 3, ScalarInteger(its));
+  SET_VECTOR_ELT(out, 4, trace);
+  SET_VECTOR_ELT(out, 5, VECTOR_ELT(par, 0));
+  SET_VECTOR_ELT(out, 6, VECTOR_ELT(par, 1));
+  UNPROTECT(5);
+  return out;
+}
+
+/* m_step (CF:397-437), both branches, against a hyper-posterior given by the caller:
+ * list(theta_0 (2), theta_i (3 x M)). */
+SEXP magmahip_m_step(SEXP hx, SEXP mean, SEXP cov, SEXP m0, SEXP theta0, SEXP theta_i, SEXP common_hp) {
+  native *h = get_native(hx);
+  if (LENGTH(theta_i) != 3 * h->M) Rf_error("magmahip: theta_i must be 3 x M");
+  SEXP th0 = PROTECT(allocVector(REALSXP, 2));
+  SEXP thi = PROTECT(allocMatrix(REALSXP, 3, h->M));
+  int rc = magma_set_m0(h->ctx, h->ds, REAL(m0), LENGTH(m0));
+  if (!rc) rc = magma_set_mean_cov(h->ctx, h->ds, REAL(mean), REAL(cov), h->N);
+  if (!rc) rc = magma_m_step(h->ctx, h->ds, REAL(theta0), REAL(theta_i), asLogical(common_hp), NULL,
+                             REAL(th0), REAL(thi));
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(out, 0, th0);
+  SET_VECTOR_ELT(out, 1, thi);
+  UNPROTECT(3);
+  return out;
+}
+
+/* train_new_gp (MG:84-104): t / y sorted by t, mean and cov block at t -> c(theta1, theta2, sigma) */
+SEXP magmahip_train_new_gp(SEXP t, SEXP y, SEXP mean, SEXP cov, SEXP ini) {
+  magma_ctx *ctx = NULL;
+  const int n = LENGTH(t);
+  SEXP out = PROTECT(allocVector(REALSXP, 3));
+  int rc = magma_ctx_create(&ctx, 0);
+  if (!rc)
+    rc = magma_train_new_gp(ctx, n, REAL(t), REAL(y), REAL(mean), isNull(cov) ? NULL : REAL(cov), n,
+                            REAL(ini), NULL, REAL(out), NULL);
+  if (ctx) magma_ctx_destroy(ctx);
+  if (rc) {
+    UNPROTECT(1);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  UNPROTECT(1);
+  return out;
+}
+
+/* posterior_mu (MG:107-133) + pred_gp (MG:135-181) for ONE new individual in one call, the
+ * hyper-posterior never leaving the device: list(Mean, Var) at the (sorted) target timestamps. */
+SEXP magmahip_posterior_pred(SEXP off, SEXP t, SEXP y, SEXP extra_t, SEXP theta0, SEXP theta_i,
+                             SEXP pen, SEXP m0, SEXP tn, SEXP yn, SEXP ts, SEXP theta_new) {
+  const int M = LENGTH(off) - 1, T = LENGTH(ts), n = LENGTH(tn);
+  magma_ctx *ctx = NULL;
+  magma_dataset *ds = NULL;
+  int64_t *off64 = (int64_t *)malloc(sizeof(int64_t) * (M + 1));
+  SEXP pm = PROTECT(allocVector(REALSXP, T));
+  SEXP pv = PROTECT(allocVector(REALSXP, T));
+  int rc = off64 ? 0 : 1, N = 0, info = 0, pinfo = 0;
+  if (!rc) {
+    for (int i = 0; i <= M; ++i) off64[i] = INTEGER(off)[i];
+    rc = magma_ctx_create(&ctx, 0);
+  }
+  if (!rc)
+    rc = magma_posterior_mu(ctx, &ds, M, M, 0, off64, REAL(t), REAL(y), LENGTH(extra_t), REAL(extra_t),
+                            REAL(theta0), REAL(theta_i), LENGTH(theta_i) == 3 ? 0 : 3, REAL(pen)[0],
+                            REAL(m0), &N, &info);
+  if (!rc && info == 0) {
+    const int64_t on[2] = {0, n}, ot[2] = {0, T};
+    rc = magma_pred_gp_resident(ctx, ds, 1, on, REAL(tn), REAL(yn), ot, REAL(ts), REAL(theta_new), 0,
+                                REAL(pm), REAL(pv), &pinfo);
+  }
+  free(off64);
+  if (ds) magma_dataset_destroy(ds);
+  if (ctx) magma_ctx_destroy(ctx);
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, pm);
+  SET_VECTOR_ELT(out, 1, pv);
+  SET_VECTOR_ELT(out, 2, ScalarInteger(info != 0 ? info : pinfo)); /* != 0: use the R bodies */
+  UNPROTECT(3);
+  return out;
+}
+
 static const R_CallMethodDef call_methods[] = {
+    {"magmahip_dataset", (DL_FUNC)&magmahip_dataset, 4},
+    {"magmahip_training", (DL_FUNC)&magmahip_training, 5},
+    {"magmahip_m_step", (DL_FUNC)&magmahip_m_step, 7},
+    {"magmahip_train_new_gp", (DL_FUNC)&magmahip_train_new_gp, 5},
+    {"magmahip_posterior_pred", (DL_FUNC)&magmahip_posterior_pred, 12},
     {"magmahip_session", (DL_FUNC)&magmahip_session, 5},
     {"magmahip_e_step", (DL_FUNC)&magmahip_e_step, 5},
     {"magmahip_set_posterior", (DL_FUNC)&magmahip_set_posterior, 3},
