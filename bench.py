@@ -174,7 +174,34 @@ def main():
             box.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
         dist.broadcast(box, 0)
         uid = bytes(box.cpu().numpy().tobytes())
-    eng = NativeEngine(ds, rank=rank, world=world, unique_id=uid, device=torch.device("cuda", local))
+    comm_kind = "none" if world == 1 else "rccl (inside libmagma_hip.so)"
+    eng = None
+    if world > 1 and os.environ.get("MAGMA_BENCH_COMM", "rccl") == "rccl":
+        try:
+            eng = NativeEngine(ds, rank=rank, world=world, unique_id=uid,
+                               device=torch.device("cuda", local))
+        except _lib.MagmaHipError as e:  # e.g. librccl not resolvable by dlopen on this box
+            print(f"[bench rank {rank}] RCCL communicator inside the library failed: {e}", file=sys.stderr)
+        ok = torch.tensor([1 if eng is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and eng is not None:
+            eng.close()
+            eng = None
+    if eng is None and world > 1:
+        # fallback: the library's callback communicator on the launcher's process group (same EM
+        # code path; the sum itself is then torch.distributed's all_reduce on RCCL)
+        from magma_amd.native import device_tensor
+        comm_kind = "callback -> torch.distributed all_reduce (RCCL)"
+
+        def allreduce(ptr, count, stream=None):
+            torch.cuda.synchronize()
+            tens = device_tensor(ptr, count)
+            dist.all_reduce(tens)
+            torch.cuda.synchronize()
+        eng = NativeEngine(ds, rank=rank, world=world, allreduce=allreduce,
+                           device=torch.device("cuda", local))
+    elif eng is None:
+        eng = NativeEngine(ds, rank=rank, world=world, device=torch.device("cuda", local))
     common = cfg["common_hp"]
     ini0, ini_i = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (ds.M, 1))
 
@@ -321,7 +348,7 @@ def main():
                                          else "continuing after the warmup iterations")),
                        "M_per_gpu": Mloc, "theta0_evals_per_step": e0,
                        "indiv_eval_rounds_per_step": ei, "indiv_evals_per_step": n_evals / n_steps,
-                       "parallelism": f"dp{world}", "driver": "native (magma_em_iteration / magma_training)",
+                       "parallelism": f"dp{world}", "communicator": comm_kind, "driver": "native (magma_em_iteration / magma_training)",
                        "logLL_trace": lls, "eps_trace": epss, "step_ms": step_ms},
             "roofline": roof, "fit": fit, "steady_state": steady, "rates": rates,
             "kernel_classes": prof,
