@@ -157,6 +157,8 @@ def main():
     from magma_amd.native import NativeEngine, unique_id
     from magma_amd.synth import simu_arrays
     lib = _lib.load()
+    if os.environ.get("MAGMA_DEDUP", "1") == "0":  # C2: batched sum instead of one inverse per evaluation
+        _lib.call("magma_set_option", b"dedup", 0)
 
     cfg = dict(CONFIGS[args.config])
     if args.config == "c5" and args.scaling == "strong":

@@ -61,10 +61,12 @@ int magma_stream_sync(void* stream);
  * cov blocks (magma_indiv_gather_cov), 10 device-resident per-individual M-step. */
 int magma_prof_enable(int on);
 int magma_prof_reset(void);
-/* Tunables. "resident_max_workgroups": cap on the grid of magma_indiv_mstep_resident (0 = one
- * workgroup per individual; otherwise workgroups take individuals in a grid-stride loop). Its
- * wavefronts fill a SIMD's register file: a cap of 2 per CU leaves half of every CU to the
- * kernels of other streams (the theta_0 chain). */
+/* Tunables. "resident_max_workgroups": cap on the grid of magma_indiv_mstep_resident (0 = none:
+ * one four-wavefront workgroup per compute unit; its wavefronts fill a SIMD's register file, so
+ * a cap of G leaves the other compute units to the kernels of other streams -- the theta_0
+ * chain). "dag_workgroups": workgroups of the one-launch dense inverse (0 = launch-per-step
+ * path). "dedup" (default 1): with identical timestamps and common hyper-parameters the driver
+ * inverts K once per evaluation (Computing_functions.R:221-224, 347-350); 0 = batched sum. */
 int magma_set_option(const char* name, long value);
 int magma_prof_get(int id, int* h_count, double* h_total_ms);
 

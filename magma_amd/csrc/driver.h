@@ -39,6 +39,15 @@ int launch_trace(int N, int64_t ld, const double* A, double* out, hipStream_t st
 int launch_gather_block(int n, int np, const int* idx, const double* cov, int64_t ldc,
                         const double* mean, double* C, double* m, hipStream_t st);
 
+// common timestamps + common hyper-parameters (CF:221-224, 347-350): S = (1/M) sum_i r_i r_i'
+// (n x n), the packed C' = C + S of the pseudo-individual that stands for all M, and its outputs
+// y' = mean at the timestamps (small.hip, dedup_*). y: M x n outputs, idx: the n grid positions.
+int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx, const double* mean,
+                         const double* cov, int64_t ldc, double* S, double* cpack, double* y_out,
+                         hipStream_t st);
+bool dedup_enabled();
+void set_dedup(bool on);
+
 // out4 = (sum f, sum g[:,0], sum g[:,1], sum g[:,2]) over M entries, fixed order (g may be null)
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st);
 // lower 64 x 64 tiles of the Np x Np matrix P <-> contiguous buffer (tile (i, j <= i) at

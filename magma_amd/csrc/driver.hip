@@ -143,6 +143,10 @@ struct magma_dataset {
   DevBuf plist;  // lower tiles of the theta_0 gradient owned by this rank
   int nplist = 0;
   bool cpack_ok = false, have_order = false;
+  // identical timestamps for all of this rank's individuals (CF:221-224, 347-350): with common
+  // hyper-parameters their summed objective is M x one pseudo-individual's (small.hip, dedup_*)
+  bool common_times = false, dedup_ok = false;
+  DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
   double a0_key[3] = {0, 0, 0};
   std::vector<int> last_nfev;
@@ -309,7 +313,36 @@ int sum_fi(magma_ctx* c, magma_dataset* d, const double* h_theta_i, int stride, 
   hipStream_t st = c->main;
   double* fs = d->fsum.as<double>();
   MAGMA_CHECK_HIP(hipMemsetAsync(fs, 0, 4 * sizeof(double), st));
-  if (d->M > 0) {
+  if (stride == 0 && d->common_times && dedup_enabled()) {
+    // one pseudo-individual stands for all M (see dedup_outer_kernel): its f, g times M
+    const int n0 = (int)d->h_off[1];
+    if (int rc = set_theta(d, h_theta_i, 0, st)) return rc;
+    if (!d->dedup_ok) {
+      if (int rc = launch_dedup_prepare((int)d->M, n0, d->nmax, d->y.as<double>(), d->idx.as<int>(),
+                                        d->mean.as<double>(), d->P.as<double>(), d->Np,
+                                        d->ddS.as<double>(), d->ddC.as<double>(), d->ddy.as<double>(), st))
+        return rc;
+      d->dedup_ok = true;
+    }
+    if (int rc = magma_indiv_eval(0, 1, d->nmax, d->ddoff.as<int64_t>(), d->t.as<double>(),
+                                  d->ddy.as<double>(), d->idx.as<int>(), d->theta.as<double>(), 0,
+                                  d->mean.as<double>(), d->ddC.as<double>(), want_grad, nullptr, 0,
+                                  d->ddf.as<double>(), d->ddg.as<double>(), d->ddinfo.as<int>(), st))
+      return rc;
+    if (want_grad) d->stats.indiv_evals += 1;
+    double loc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (int rc = d2h(loc, d->ddf.p, sizeof(double), st)) return rc;
+    if (want_grad)
+      if (int rc = d2h(loc + 1, d->ddg.p, 3 * sizeof(double), st)) return rc;
+    if (int rc = sync(st)) return rc;
+    for (int q = 0; q < 4; ++q) loc[q] *= (double)d->M;
+    if (!c->has_comm()) {
+      std::copy(loc, loc + 4, out4);
+      return 0;
+    }
+    if (int rc = h2d(fs, loc, 4 * sizeof(double), st)) return rc;
+    if (int rc = sync(st)) return rc;
+  } else if (d->M > 0) {
     if (int rc = set_theta(d, h_theta_i, stride, st)) return rc;
     if (int rc = ensure_cpack(d, st)) return rc;
     if (int rc = magma_indiv_eval(0, (int)d->M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
@@ -525,6 +558,22 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
       (rc = upload(d->y, d->h_y)) || (rc = upload(d->idx, d->h_idx)) || (rc = upload(d->grid, d->h_grid)))
     return rc;
   if ((rc = build_gather_lists(d))) return rc;
+  d->common_times = d->large.empty() && M > 1;
+  for (int64_t i = 1; i < M && d->common_times; ++i) {
+    const int64_t n0 = d->h_off[1], o = d->h_off[(size_t)i];
+    d->common_times = (d->h_off[(size_t)i + 1] - o == n0) &&
+                      std::equal(d->h_t.begin(), d->h_t.begin() + n0, d->h_t.begin() + o);
+  }
+  if (d->common_times) {
+    const size_t n0 = (size_t)d->h_off[1];
+    const std::vector<int64_t> o1 = {0, (int64_t)n0};
+    if ((rc = d->ddS.alloc(sizeof(double) * n0 * n0)) ||
+        (rc = d->ddC.alloc(sizeof(double) * (size_t)magma_cpack_stride(d->nmax))) ||
+        (rc = d->ddy.alloc(sizeof(double) * n0)) || (rc = upload(d->ddoff, o1)) ||
+        (rc = d->ddf.alloc(sizeof(double))) || (rc = d->ddg.alloc(sizeof(double) * 3)) ||
+        (rc = d->ddinfo.alloc(sizeof(int))))
+      return rc;
+  }
   const size_t Mb = (size_t)std::max<int64_t>(M, 1), Np = (size_t)d->Np;
   const size_t Mt = (size_t)std::max<int64_t>(M_total, 1);
   const int nt = d->Np / 64;
@@ -633,6 +682,7 @@ int magma_set_mean_cov(magma_ctx* c, magma_dataset* d, const double* h_mean, con
   MAGMA_CHECK_HIP(hipMemcpy2DAsync(d->P.p, (size_t)d->Np * sizeof(double), h_cov, (size_t)ld * sizeof(double),
                                    (size_t)d->N * sizeof(double), (size_t)d->N, hipMemcpyHostToDevice, st));
   d->cpack_ok = false;
+  d->dedup_ok = false;
   return sync(st);
 }
 
@@ -661,6 +711,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   if ((rc = set_m0(d, h_m0, n_m0, st))) return rc;
   if ((rc = set_theta(d, h_theta_i, theta_stride, st))) return rc;
   d->cpack_ok = false;
+  d->dedup_ok = false;
   const size_t Np = (size_t)d->Np;
   MAGMA_CHECK_HIP(hipMemsetAsync(d->P.p, 0, sizeof(double) * Np * Np, st));
   MAGMA_CHECK_HIP(hipMemsetAsync(d->w.p, 0, sizeof(double) * Np, st));
@@ -735,7 +786,11 @@ int magma_logl_monitoring(magma_ctx* c, magma_dataset* d, const double* h_theta0
   const double pen = mean_sigma(d, h_theta_i, theta_stride, 1.0);  // CF:251
   double ll0 = 0.0, s4[4];
   if (int rc = theta0_f(c, d, h_theta0, pen, &ll0)) return rc;
-  if (int rc = sum_fi(c, d, h_theta_i, theta_stride, 0, s4)) return rc;
+  // equal rows = common hyper-parameters (CF:245-249 then takes the *_common_hp sum)
+  bool same = theta_stride == 3 && d->common_times;
+  for (int64_t i = 1; i < d->M_total && same; ++i)
+    same = std::equal(h_theta_i, h_theta_i + 3, h_theta_i + 3 * i);
+  if (int rc = sum_fi(c, d, h_theta_i, same ? 0 : theta_stride, 0, s4)) return rc;
   *h_out = -ll0 - s4[0];
   return 0;
 }

@@ -62,71 +62,6 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define STAMP_FLUSH()
 #endif
 
-// ------------------------------------------------------------------ row build
-// a[c] = K[r][c] for the SE kernel: off-diagonal exp(th1 - h (t_r - t_c)^2), diagonal
-// exp(th1) + sigma^2 (CF:76,103: as.matrix(dist) has a zero diagonal). Identity padding.
-template <int NMAX>
-__device__ __forceinline__ void build_row(double (&a)[NMAX], int lane, int n, double tr,
-                                          const double* tbuf, const SEParams& p) {
-  const bool rv = lane < n;
-#pragma unroll
-  for (int c = 0; c < NMAX; ++c) {
-    double d = tr - tbuf[c];
-    double v = exp(p.th1 - p.h * d * d);
-    v = (c == lane) ? (p.eth1 + p.sig2) : v;
-    a[c] = (rv && c < n) ? v : ((c == lane) ? 1.0 : 0.0);
-    // keep the unrolled exp() bodies sequential: interleaving all of them spills registers
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// ------------------------------------------------------------------ symmetric sweep
-// In: a = row `lane` of SPD matrix A (identity padded). Out: a = row of A^-1.
-// Stored row r is kept as true_row / s_r so that the pivot row needs no per-element scaling.
-// colbuf: 64 doubles of LDS owned by this wavefront. Returns log|A| and info (0 = SPD,
-// k+1 = first non-positive pivot, like LAPACK dpotrf's info).
-template <int NMAX>
-__device__ __forceinline__ void sweep_inverse(double (&a)[NMAX], int lane, double* colbuf,
-                                              double& logdet, int& info) {
-  double s = 1.0;
-  double pm = 1.0;
-  int pe = 0;
-  info = 0;
-#pragma unroll
-  for (int k = 0; k < NMAX; ++k) {
-    colbuf[lane] = a[k] * s;  // true column k == true row k (symmetry)
-    __syncthreads();
-    double d = colbuf[k];
-    const bool ok = (d > 0.0) && (d < 1.7e308);  // uniform across the wavefront
-    info = (!ok && info == 0) ? k + 1 : info;
-    d = ok ? d : 1.0;
-    int e;
-    pm *= frexp(d, &e);
-    pe += e;
-    const double pinv = fast_rcp(d);
-    const bool isk = (lane == k);
-    const double f = isk ? 0.0 : a[k] * pinv;
-#pragma unroll
-    for (int c = 0; c < NMAX; c += 2) {
-      double2 b = *reinterpret_cast<const double2*>(&colbuf[c]);
-      a[c] = fma(-f, b.x, a[c]);
-      a[c + 1] = fma(-f, b.y, a[c + 1]);
-    }
-    a[k] = isk ? -1.0 : f;
-    s = isk ? pinv : s;
-    __syncthreads();
-  }
-  const double ms = -s;  // all pivots swept: stored*s = -A^-1
-#pragma unroll
-  for (int c = 0; c < NMAX; ++c) {
-    a[c] *= ms;
-    // pin the finished row: otherwise hipcc sinks each element's whole update chain into the
-    // callers' conditional stores and spills every broadcast value of every step
-    asm volatile("" : "+v"(a[c]));
-  }
-  logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818;
-}
-
 // ------------------------------------------------------------------ K1: covariance only
 // One workgroup per individual; timestamps staged in LDS, coalesced column-major writes.
 __global__ __launch_bounds__(256) void se_cov_batched_kernel(
@@ -567,6 +502,42 @@ __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
       out[e] = (r < n && c < n) ? cov[(int64_t)ibuf[c] * ldc + ibuf[r]] : 0.0;
     }
   }
+}
+
+// ------------------------------------------------------------------ common timestamps + common HPs
+// CF:221-224, 347-350: with identical timestamps and common hyper-parameters the reference
+// inverts K once per evaluation and only the residuals differ between individuals. The sum over
+// the M individuals of the objective (CF:203-234) and of its gradient (CF:334-368) is then M
+// times the objective / gradient of ONE pseudo-individual with residual 0 and
+// C' = C + (1/M) sum_i r_i r_i' in place of C:
+//   sum_i [r_i' K^-1 r_i + tr(K^-1 C)] = M tr(K^-1 C'),
+//   sum_i [a_i a_i' + K^-1 (C K^-1 - I)] = M [K^-1 C' K^-1 - K^-1],  a_i = K^-1 r_i.
+// dedup_outer_kernel forms S / M (fixed summation order: i ascending), dedup_pack_kernel the
+// packed C' (layout of indiv_gather_cov_kernel) and the pseudo-individual's outputs y' = mean
+// at its timestamps (so that its residual is exactly 0).
+__global__ __launch_bounds__(64) void dedup_outer_kernel(
+    int M, int n, const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ mean, double* __restrict__ S) {
+  const int b = blockIdx.x, a = threadIdx.x;
+  if (a >= n || b >= n) return;
+  const double ma = mean[idx[a]], mb = mean[idx[b]];
+  double acc = 0.0;
+  for (int i = 0; i < M; ++i)
+    acc = fma(y[(int64_t)i * n + a] - ma, y[(int64_t)i * n + b] - mb, acc);
+  S[a + (int64_t)n * b] = acc / (double)M;
+}
+
+__global__ __launch_bounds__(256) void dedup_pack_kernel(
+    int n, const int* __restrict__ idx, const double* __restrict__ cov, int64_t ldc,
+    const double* __restrict__ S, const double* __restrict__ mean, double* __restrict__ cpack,
+    double* __restrict__ y_out, int nt, int nc) {
+  const int tot = 16 * nt * nc;
+  for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+    const int it = e % nt, ln = (e / nt) & 63, kk = e / (64 * nt);
+    const int r = 16 * it + (ln & 15), c = 4 * kk + (ln >> 4);
+    cpack[e] = (r < n && c < n) ? cov[(int64_t)idx[c] * ldc + idx[r]] + S[r + (int64_t)n * c] : 0.0;
+  }
+  if ((int)threadIdx.x < n) y_out[threadIdx.x] = mean[idx[threadIdx.x]];
 }
 
 // ------------------------------------------------------------------ E-step, deterministic route
@@ -1064,7 +1035,89 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
   __shared__ double zbuf[64];                                  \
   __shared__ double kbuf[64];                                  \
   __shared__ int ibuf[64];                                     \
-  __shared__ __attribute__((aligned(16))) double colbuf[64]
+  extern __shared__ __attribute__((aligned(16))) double Ks[]
+
+// cov_tn_tn = K(tn) + C[in, in] (MG:172-173; C = 0 without cov) in accumulator layout, scaled to
+// a diagonal <= 1, inverted with the blocked MFMA sweep (mfma_sweep.h), left in LDS as
+// Ks[r * NMAX + c] (symmetric; NMAX * NMAX + 16 doubles). Ends with a wave_sync().
+template <int NMAX>
+__device__ __forceinline__ void pred_inverse_to_lds(int lane, int n, const SEParams& p,
+                                                    const double* tbuf, const int* ibuf,
+                                                    const double* __restrict__ cov, int64_t ldc,
+                                                    double* Ks, int& info) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4, LD = NMAX;
+  static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
+  const int l = lane & 15, g = lane >> 4;
+  v4d A[NT][NT];
+  double tcol[NT];
+  int icol[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    tcol[jt] = tbuf[16 * jt + l];
+    icol[jt] = ibuf[16 * jt + l];
+  }
+  double dm = 0.0;
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
+        continue;
+      }
+      const int r = 16 * it + 4 * v + g;
+      const double trow = tbuf[r];
+      const int irow = ibuf[r];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        const bool in = r < n && c < n;
+        const double d = trow - tcol[jt];
+        double kv = exp(p.th1 - p.h * d * d);
+        kv = (r == c) ? (p.eth1 + p.sig2) : kv;
+        if (cov != nullptr && in) kv += cov[(int64_t)icol[jt] * ldc + irow];
+        A[it][jt][v] = in ? kv : 0.0;
+        dm = fmax(dm, (in && r == c) ? kv : 0.0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o));
+  // (a non-positive diagonal cannot be scaled; the sweep then flags the matrix by itself)
+  const double sc = (dm > 0.0 && dm < 1.7e308) ? 1.0 / dm : 1.0;
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) continue;
+      const int r = 16 * it + 4 * v + g;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        A[it][jt][v] = (r < n && c < n) ? A[it][jt][v] * sc : ((r == c) ? 1.0 : 0.0);
+      }
+    }
+  double pm = 1.0;
+  int pe = 0;
+  info = 0;
+  wave_sync();
+  mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * it + 4 * v >= NMAX) continue;
+      const int r = 16 * it + 4 * v + g;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int c = 16 * jt + l;
+        if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
+      }
+    }
+  wave_sync();
+}
 
 // mean_grid != nullptr: the mean process is given on cov's grid and gathered through idx_n /
 // idx_t (the device-resident route of the batched entry point); else mean_obs / mean_pred hold it.
@@ -1077,7 +1130,7 @@ __device__ __forceinline__ void pred_gp_body(
     const double* __restrict__ cov, int64_t ldc,
     const double* __restrict__ theta, double* __restrict__ out_mean,
     double* __restrict__ out_var, int* __restrict__ info_out, int chunk_id, int chunk,
-    double* tbuf, double* zbuf, double* kbuf, int* ibuf, double* colbuf) {
+    double* tbuf, double* zbuf, double* kbuf, int* ibuf, double* Ks) {
   const int lane = threadIdx.x;
   const double sigma = theta[2];
   const SEParams p = se_params(theta[0], theta[1], sigma);
@@ -1095,21 +1148,15 @@ __device__ __forceinline__ void pred_gp_body(
   zbuf[lane] = zr;
   ibuf[lane] = ir;
   __syncthreads();
-  double a[NMAX];
-  build_row<NMAX>(a, lane, n, tr, tbuf, p);
-  if (cov != nullptr) {
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c)
-      if (rv && c < n) a[c] += cov[(int64_t)ibuf[c] * ldc + ir];
-  }
-  __syncthreads();
-  double logdet;
   int info;
-  sweep_inverse<NMAX>(a, lane, colbuf, logdet, info);
+  pred_inverse_to_lds<NMAX>(lane, n, p, tbuf, ibuf, cov, ldc, Ks, info);
   if (lane == 0 && chunk_id == 0) info_out[0] = info;
+  // lane r owns row r = column r of the inverse: Ks[c * NMAX + r] is conflict free
+  const int lr = lane < NMAX ? lane : 0;
   double alpha = 0.0;
 #pragma unroll
-  for (int c = 0; c < NMAX; ++c) alpha = fma(a[c], zbuf[c], alpha);
+  for (int c = 0; c < NMAX; ++c) alpha = fma(Ks[c * NMAX + lr], zbuf[c], alpha);
+  alpha = rv ? alpha : 0.0;
   const int j0 = chunk_id * chunk;
   const int j1 = min(T, j0 + chunk);
   for (int j = j0; j < j1; ++j) {
@@ -1123,7 +1170,7 @@ __device__ __forceinline__ void pred_gp_body(
     __syncthreads();
     double u = 0.0;
 #pragma unroll
-    for (int c = 0; c < NMAX; ++c) u = fma(a[c], kbuf[c], u);
+    for (int c = 0; c < NMAX; ++c) u = fma(Ks[c * NMAX + lr], kbuf[c], u);
     const double q = wave_sum(kv * u);
     const double m = wave_sum(kv * alpha);
     if (lane == 0) {
@@ -1146,7 +1193,7 @@ __global__ __launch_bounds__(64) void pred_gp_kernel(
     double* __restrict__ out_var, int* __restrict__ info_out, int chunk) {
   PRED_GP_LDS;
   pred_gp_body<NMAX, false>(n, tn, yn, mean_obs, idx_n, T, ts, mean_pred, idx_t, nullptr, cov, ldc, theta,
-                     out_mean, out_var, info_out, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, colbuf);
+                     out_mean, out_var, info_out, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, Ks);
 }
 
 // pred_gp for B new individuals against ONE device-resident hyper-posterior (the
@@ -1169,7 +1216,7 @@ __global__ __launch_bounds__(64) void pred_gp_batched_kernel(
   if ((int)blockIdx.x * chunk >= T && blockIdx.x != 0) return;  // (chunk 0 always reports info)
   pred_gp_body<NMAX, true>(n, tn + on, yn + on, nullptr, idx_n + on, T, ts + ot, nullptr, idx_t + ot,
                      mean_grid, cov, ldc, theta + (int64_t)b * tstride, out_mean + ot, out_var + ot,
-                     info_out + b, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, colbuf);
+                     info_out + b, blockIdx.x, chunk, tbuf, zbuf, kbuf, ibuf, Ks);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1384,6 +1431,21 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
   return rc;
 }
 
+static std::atomic<bool> g_dedup{true};
+bool dedup_enabled() { return g_dedup.load(); }
+void set_dedup(bool on) { g_dedup.store(on); }
+
+int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx, const double* mean,
+                         const double* cov, int64_t ldc, double* S, double* cpack, double* y_out,
+                         hipStream_t st) {
+  if (M < 1 || n < 1 || n > MAGMA_NSMALL_MAX) return fail(2, "dedup: bad sizes");
+  const int nc = small_template_nmax(nmax), nt = (nc + 15) / 16;
+  hipLaunchKernelGGL(dedup_outer_kernel, dim3((unsigned)n), dim3(64), 0, st, M, n, y, idx, mean, S);
+  hipLaunchKernelGGL(dedup_pack_kernel, dim3(1), dim3(256), 0, st, n, idx, cov, ldc, S, mean, cpack,
+                     y_out, nt, nc);
+  return check_hip(hipGetLastError(), "dedup_prepare");
+}
+
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st) {
   if (M <= 0) return 0;
@@ -1401,7 +1463,8 @@ int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean
   const int chunk = 8;
   const int grid = (T + chunk - 1) / chunk;
 #define CALL(NM)                                                                            \
-  hipLaunchKernelGGL(pred_gp_kernel<NM>, dim3(grid), dim3(64), 0, st, n, tn, yn, mean_obs, \
+  hipLaunchKernelGGL(pred_gp_kernel<NM>, dim3(grid), dim3(64),                              \
+                     (NM * NM + 16) * sizeof(double), st, n, tn, yn, mean_obs,               \
                      idx_n, T, ts, mean_pred, idx_t, cov, ldc, theta, out_mean, out_var,   \
                      info, chunk)
   MAGMA_DISPATCH_NMAX(n, CALL);
@@ -1418,7 +1481,8 @@ int launch_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, cons
   const int chunk = 8;
   const int gx = tmax > 0 ? (tmax + chunk - 1) / chunk : 1;
 #define CALL(NM)                                                                               \
-  hipLaunchKernelGGL(pred_gp_batched_kernel<NM>, dim3(gx, B), dim3(64), 0, st, off_n, tn, yn,  \
+  hipLaunchKernelGGL(pred_gp_batched_kernel<NM>, dim3(gx, B), dim3(64),                        \
+                     (NM * NM + 16) * sizeof(double), st, off_n, tn, yn,                        \
                      idx_n, off_t, ts, idx_t, mean_grid, cov, ldc, theta, tstride, out_mean,   \
                      out_var, info, chunk)
   MAGMA_DISPATCH_NMAX(nmax, CALL);

@@ -377,3 +377,48 @@ def test_individuals_with_more_than_64_observations(m):
         assert np.abs(got[i][1] - ref_inv[i][1]).max() < 1e-9 * np.abs(ref_inv[i][1]).max(), i
     with pytest.raises(ValueError, match="NativeEngine"):
         m.Engine(ds)
+
+
+def test_common_times_common_hp_inverts_once(m):
+    """BASELINE config 2's shape (all individuals on one grid, common HPs): CF:221-224, 347-350
+    invert K once per evaluation; the driver evaluates ONE pseudo-individual with
+    C' = C + mean_i(r_i r_i') and multiplies by M (small.hip, dedup_*). Against the batched sum over
+    individuals (option dedup = 0) and the oracle's *_common_hp functions."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_db
+    db, a = simu_db(M=60, n=30, N=30, common_times=True, common_hp=True, seed=12)
+    ds = m.Dataset(db)
+    th0 = np.array([0.9, 0.7])
+    thi = np.tile([0.8, 0.6, 0.3], (ds.M, 1))
+    out = {}
+    try:
+        for dd in (1, 0):
+            _lib.call("magma_set_option", b"dedup", dd)
+            eng = NativeEngine(ds)
+            assert eng.e_step(th0, thi, 0.3, 0.1) == 0
+            eng.reset_stats()
+            ll = eng.logL_monitoring(th0, thi)
+            n0, ni = eng.m_step(th0, thi, True)
+            out[dd] = dict(ll=ll, n0=n0, ni=ni, evals=eng.stats["indiv_evals"],
+                           ce=eng.stats["common_evals"], mean=eng.get_mean(), cov=eng.get_cov())
+            eng.close()
+    finally:
+        _lib.call("magma_set_option", b"dedup", 1)
+    d1, d0 = out[1], out[0]
+    # one evaluation per optimiser step instead of M
+    assert d1["ce"] == d0["ce"] and d1["evals"] * ds.M == d0["evals"]
+    assert abs(d1["ll"] - d0["ll"]) < 1e-11 * abs(d0["ll"])
+    assert np.abs(d1["n0"] - d0["n0"]).max() == 0.0 and np.abs(d1["ni"] - d0["ni"]).max() < 1e-6
+    # the objective and gradient themselves against the oracle (CF:203-234, 334-368)
+    labels = ds.grid
+    mean_db = {"Timestamp": labels, "Output": d1["mean"]}
+    hp3 = np.array([0.8, 0.6, 0.3])
+    f_o = orc.logL_GP_mod_common_hp(hp3, db, mean_db, orc.kernel, (labels, d1["cov"]))
+    hp = {"theta_0": th0, "theta_i": {i: thi[k] for k, i in enumerate(ds.ids)}}
+    ll_o = orc.logL_monitoring(hp, db, orc.kernel, orc.kernel, mean_db, (labels, d1["cov"]), 0.1)
+    assert abs(d1["ll"] - ll_o) < 1e-9 * abs(ll_o), (d1["ll"], ll_o, f_o)
+    # the optimum found is a stationary point of the oracle's summed objective
+    g_o = orc.gr_GP_mod_common_hp(d1["ni"][0], db, mean_db, orc.kernel, (labels, d1["cov"]))
+    f_new = orc.logL_GP_mod_common_hp(d1["ni"][0], db, mean_db, orc.kernel, (labels, d1["cov"]))
+    assert f_new < f_o and np.abs(g_o).max() < 1e-3 * max(1.0, abs(f_new))
