@@ -560,6 +560,10 @@ int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, co
 
 int magma_set_option(const char* name, long value) {
   if (!name) return fail(2, "option name is NULL");
+  if (std::string(name) == "prefetch") {  // next E-step's sums started under the monitoring call
+    set_prefetch(value != 0);
+    return 0;
+  }
   if (std::string(name) == "dedup") {  // CF:221-224: invert once for identical timestamps
     set_dedup(value != 0);
     return 0;

@@ -47,6 +47,8 @@ int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx
                          hipStream_t st);
 bool dedup_enabled();
 void set_dedup(bool on);
+bool prefetch_enabled();
+void set_prefetch(bool on);
 
 // out4 = (sum f, sum g[:,0], sum g[:,1], sum g[:,2]) over M entries, fixed order (g may be null)
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st);

@@ -146,6 +146,13 @@ struct magma_dataset {
   // identical timestamps for all of this rank's individuals (CF:221-224, 347-350): with common
   // hyper-parameters their summed objective is M x one pseudo-individual's (small.hip, dedup_*)
   bool common_times = false, dedup_ok = false;
+  // the NEXT E-step's sums over individuals (they depend on theta_i only), started on the side
+  // stream next to the monitoring call that ends an EM iteration (prefetch_estep_sums)
+  DevBuf P2, w2, theta2, info2, f2;
+  hipEvent_t pre_ev = nullptr;
+  bool pre_valid = false, pre_issued = false;
+  std::vector<double> pre_theta;
+  ~magma_dataset() { if (pre_ev) (void)hipEventDestroy(pre_ev); }
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
   double a0_key[3] = {0, 0, 0};
@@ -303,6 +310,38 @@ int ensure_cpack(magma_dataset* d, hipStream_t st) {
                                       d->P.as<double>(), d->N, d->cpack.as<double>(), st))
     return rc;
   d->cpack_ok = true;
+  return 0;
+}
+
+// The sums over individuals of the next E-step (CF:382-391: sum_i scatter K_i^-1, sum_i K_i^-1 y_i)
+// depend on theta_i alone: an EM iteration starts them on the side stream as soon as its M-step
+// has the new theta_i, next to the (latency-bound) dense inverse of its last monitoring call,
+// into a second pair of buffers. The E-step that follows takes them if it is called with these
+// very hyper-parameters (compared value by value), else computes its own.
+int prefetch_estep_sums(magma_ctx* c, magma_dataset* d, const double* h_theta_i) {
+  d->pre_valid = false;
+  if (d->M == 0 || !prefetch_enabled()) return 0;
+  hipStream_t st = c->side;
+  std::vector<double> rows((size_t)(3 * d->M));
+  for (int64_t k = 0; k < d->M; ++k)
+    for (int q = 0; q < 3; ++q)
+      rows[(size_t)(3 * k + q)] = h_theta_i[3 * (d->row0 + d->small_row[(size_t)k]) + q];
+  // (pageable source: the copy has left `rows` when the call returns)
+  MAGMA_CHECK_HIP(hipMemcpyAsync(d->theta2.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  const size_t Np = (size_t)d->Np;
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->P2.p, 0, sizeof(double) * Np * Np, st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->w2.p, 0, sizeof(double) * Np, st));
+  d->pre_issued = true;
+  if (int rc = magma_estep_gather((int)d->M, d->nmax, d->off.as<int64_t>(), d->off2.as<int64_t>(),
+                                  d->t.as<double>(), d->y.as<double>(), d->theta2.as<double>(), 3,
+                                  d->Kinv.as<double>(), d->v.as<double>(), d->f2.as<double>(), d->nP,
+                                  d->ptrP.as<int64_t>(), d->srcP.as<int>(), d->tgtP.as<int64_t>(), d->nw,
+                                  d->ptrw.as<int64_t>(), d->srcw.as<int>(), d->tgtw.as<int64_t>(),
+                                  d->P2.as<double>(), d->w2.as<double>(), d->info2.as<int>(), st))
+    return rc;
+  MAGMA_CHECK_HIP(hipEventRecord(d->pre_ev, st));
+  d->pre_theta.assign(h_theta_i, h_theta_i + 3 * d->M_total);
+  d->pre_valid = true;
   return 0;
 }
 
@@ -590,6 +629,13 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
       (rc = d->rfx0.alloc(sizeof(double) * Mb)) || (rc = d->rit.alloc(sizeof(int) * Mb)) ||
       (rc = d->rnf.alloc(sizeof(int) * Mb)) || (rc = d->rst.alloc(sizeof(int) * Mb)))
     return rc;
+  if (M > 0) {
+    if ((rc = d->P2.alloc(sizeof(double) * Np * Np)) || (rc = d->w2.alloc(sizeof(double) * Np)) ||
+        (rc = d->theta2.alloc(sizeof(double) * 3 * Mb)) || (rc = d->info2.alloc(sizeof(int) * Mb)) ||
+        (rc = d->f2.alloc(sizeof(double) * Mb)))
+      return rc;
+    MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->pre_ev, hipEventDisableTiming));
+  }
   if (c->has_comm()) {
     // all-reduce staging: lower 64 x 64 tiles of P, contiguous; the gathered theta_i
     if ((rc = d->pack.alloc(sizeof(double) * (size_t)nt * (nt + 1) / 2 * 4096)) ||
@@ -713,9 +759,22 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   d->cpack_ok = false;
   d->dedup_ok = false;
   const size_t Np = (size_t)d->Np;
-  MAGMA_CHECK_HIP(hipMemsetAsync(d->P.p, 0, sizeof(double) * Np * Np, st));
-  MAGMA_CHECK_HIP(hipMemsetAsync(d->w.p, 0, sizeof(double) * Np, st));
-  if (d->M > 0 &&
+  const bool pre = d->pre_valid && theta_stride == 3 &&
+                   std::equal(d->pre_theta.begin(), d->pre_theta.end(), h_theta_i);
+  d->pre_valid = false;
+  if (d->pre_issued) {  // (also when it is not taken: it writes Kinv / v, which the sums below use)
+    MAGMA_CHECK_HIP(hipStreamWaitEvent(st, d->pre_ev, 0));
+    d->pre_issued = false;
+  }
+  if (pre) {
+    std::swap(d->P.p, d->P2.p);
+    std::swap(d->w.p, d->w2.p);
+    std::swap(d->info.p, d->info2.p);
+  } else {
+    MAGMA_CHECK_HIP(hipMemsetAsync(d->P.p, 0, sizeof(double) * Np * Np, st));
+    MAGMA_CHECK_HIP(hipMemsetAsync(d->w.p, 0, sizeof(double) * Np, st));
+  }
+  if (d->M > 0 && !pre &&
       (rc = magma_estep_gather((int)d->M, d->nmax, d->off.as<int64_t>(), d->off2.as<int64_t>(),
                                d->t.as<double>(), d->y.as<double>(), d->theta.as<double>(), theta_stride,
                                d->Kinv.as<double>(), d->v.as<double>(), d->f.as<double>(), d->nP,
@@ -1001,6 +1060,7 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   // first evaluations. logL_monitoring(new hp) (MG:60): individual terms = the optimisers' final
   // values; only the theta_0 term needs an evaluation, which leaves K_0^-1 for the next E-step.
   h_logl2[0] = -d->last_f0 - d->last_sum_fi;
+  if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) return rc;
   const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
   double ll0 = 0.0;
   if (int rc = theta0_f(c, d, h_theta0_out, sig, &ll0)) return rc;

@@ -487,19 +487,32 @@ __global__ __launch_bounds__(64) void small_slowpath_kernel(
 __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
     int M, const int64_t* __restrict__ off, const int* __restrict__ idx,
     const double* __restrict__ cov, int64_t ldc, double* __restrict__ cpack, int nt, int nc) {
+  // cov is symmetric: only the n (n + 1) / 2 elements on or below the diagonal are fetched (each
+  // one an isolated 8-byte read that costs a whole memory sector) and mirrored through LDS
+  constexpr int LDC = MAGMA_NSMALL_MAX + 1;
   __shared__ int ibuf[MAGMA_NSMALL_MAX];
+  __shared__ double Cl[MAGMA_NSMALL_MAX * LDC];
   for (int i = blockIdx.x; i < M; i += gridDim.x) {
     const int64_t o = off[i];
     const int n = (int)(off[i + 1] - o);
     __syncthreads();
     if ((int)threadIdx.x < n) ibuf[threadIdx.x] = idx[o + threadIdx.x];
     __syncthreads();
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+      const int r = e % n, c = e / n;
+      if (r >= c) {
+        const double v = cov[(int64_t)ibuf[c] * ldc + ibuf[r]];
+        Cl[r * LDC + c] = v;
+        Cl[c * LDC + r] = v;
+      }
+    }
+    __syncthreads();
     const int tot = 16 * nt * nc;
     double* out = cpack + (int64_t)i * tot;
     for (int e = threadIdx.x; e < tot; e += blockDim.x) {
       const int it = e % nt, ln = (e / nt) & 63, kk = e / (64 * nt);
       const int r = 16 * it + (ln & 15), c = 4 * kk + (ln >> 4);
-      out[e] = (r < n && c < n) ? cov[(int64_t)ibuf[c] * ldc + ibuf[r]] : 0.0;
+      out[e] = (r < n && c < n) ? Cl[r * LDC + c] : 0.0;
     }
   }
 }
@@ -1434,6 +1447,9 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
 static std::atomic<bool> g_dedup{true};
 bool dedup_enabled() { return g_dedup.load(); }
 void set_dedup(bool on) { g_dedup.store(on); }
+static std::atomic<bool> g_prefetch{true};
+bool prefetch_enabled() { return g_prefetch.load(); }
+void set_prefetch(bool on) { g_prefetch.store(on); }
 
 int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx, const double* mean,
                          const double* cov, int64_t ldc, double* S, double* cpack, double* y_out,
