@@ -35,63 +35,19 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
-// D = P^-1 and the four sweep pivots of a symmetric positive definite 4 x 4 (lower triangle in
-// p[i][j], i >= j), by LDL'. bad = index + 1 of the first pivot that is not a positive finite
-// number (0 = none); what follows a bad pivot is garbage that the caller discards (info).
-__device__ __forceinline__ void spd4_inverse(const double (&p)[4][4], double (&D)[4][4],
-                                             double (&piv)[4], int& bad) {
-  bad = 0;
-  auto fix = [&](double d, int k) {
-    const bool ok = (d > 0.0) && (d < 1.7e308);
-    bad = (!ok && bad == 0) ? k + 1 : bad;
-    return d;
-  };
-  const double d0 = fix(p[0][0], 0);
-  const double r0 = fast_rcp(d0);
-  const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
-  const double p11 = fma(-l10, p[1][0], p[1][1]);
-  const double p21 = fma(-l20, p[1][0], p[2][1]);
-  const double p31 = fma(-l30, p[1][0], p[3][1]);
-  double p22 = fma(-l20, p[2][0], p[2][2]);
-  double p32 = fma(-l30, p[2][0], p[3][2]);
-  double p33 = fma(-l30, p[3][0], p[3][3]);
-  const double d1 = fix(p11, 1);
-  const double r1 = fast_rcp(d1);
-  const double l21 = p21 * r1, l31 = p31 * r1;
-  p22 = fma(-l21, p21, p22);
-  p32 = fma(-l31, p21, p32);
-  p33 = fma(-l31, p31, p33);
-  const double d2 = fix(p22, 2);
-  const double r2 = fast_rcp(d2);
-  const double l32 = p32 * r2;
-  p33 = fma(-l32, p32, p33);
-  const double d3 = fix(p33, 3);
-  const double r3 = fast_rcp(d3);
-  piv[0] = d0; piv[1] = d1; piv[2] = d2; piv[3] = d3;
-  // M = L^-1 (unit lower)
-  const double m10 = -l10, m21 = -l21, m32 = -l32;
-  const double m20 = -fma(l21, m10, l20);
-  const double m31 = -fma(l32, m21, l31);
-  const double m30 = -fma(l32, m20, fma(l31, m10, l30));
-  // D = M' diag(r) M
-  D[3][3] = r3;
-  D[3][2] = r3 * m32;
-  D[3][1] = r3 * m31;
-  D[3][0] = r3 * m30;
-  D[2][2] = fma(m32, D[3][2], r2);
-  D[2][1] = fma(m32, D[3][1], r2 * m21);
-  D[2][0] = fma(m32, D[3][0], r2 * m20);
-  D[1][1] = fma(m31, D[3][1], fma(m21, r2 * m21, r1));
-  D[1][0] = fma(m31, D[3][0], fma(m21, r2 * m20, r1 * m10));
-  D[0][0] = fma(m30, D[3][0], fma(m20, r2 * m20, fma(m10, r1 * m10, r0)));
-  D[0][1] = D[1][0]; D[0][2] = D[2][0]; D[0][3] = D[3][0];
-  D[1][2] = D[2][1]; D[1][3] = D[3][1]; D[2][3] = D[3][2];
-}
-
 // A: NT x NT tiles (identity beyond the matrix). Pn: 64 NT doubles of LDS owned by this
 // wavefront. pm, pe accumulate det = pm * 2^pe over the pivots; info = index + 1 of the first
 // non-positive pivot (kept if already set). Single wavefront: LDS is in order per wavefront and
 // the stores/loads below may alias, so no barrier is needed.
+//
+// Software pipeline: the serial part of a block (row block -> LDS, 4 x 4 pivot block back, its
+// LDL' inverse, this lane's F' fragment: ~35 dependent FP64 operations and two LDS round trips)
+// used to sit between the rank-4 updates of consecutive blocks with the matrix core idle. Now
+// block b first updates the tile row that holds block b + 1's rows (NT MFMAs), and block b + 1's
+// serial part is issued in 12 stages with one of block b's remaining (NT - 1) NT MFMAs after each
+// (pinned with sched_barrier: the wavefront issues in order, so a VALU stage runs while the
+// MFMA issued before it occupies the matrix core). Same operations on the same operands as the
+// unpipelined form: results are bit-identical.
 template <int NT, int NK>
 __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, int g,
                                            double& pm, int& pe, int& info) {
@@ -101,48 +57,104 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
     gm[h] = (g == h) ? 1.0 : 0.0;
     asm volatile("" : "+v"(gm[h]));  // opaque: keeps the weights from being folded back to selects
   }
-#pragma unroll
-  for (int b = 0; b < NK; ++b) {
+  // serial part of block b: bq = B' fragment (row block with P - I), nf = -F' fragment.
+  // hook(k), k = 0 .. 11, is called between its stages.
+  auto serial = [&](int b, double (&bq)[NT], double (&nf)[NT], auto&& hook) {
     const int it0 = b >> 2, v0 = b & 3;
     const bool dg = (l == 4 * v0 + g);  // this lane holds a diagonal element of P (tile it0,it0)
-    double bq[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       bq[jt] = A[it0][jt][v0] - ((jt == it0 && dg) ? 1.0 : 0.0);
       Pn[(16 * jt + l) * 4 + g] = bq[jt];
     }
     __builtin_amdgcn_wave_barrier();
-    double P4[4][4], D[4][4], piv[4];
+    hook(0);
+    double p[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double2 lo = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4 + 2]);
-      P4[r][0] = lo.x; P4[r][1] = lo.y; P4[r][2] = hi.x; P4[r][3] = hi.y;
-      P4[r][r] += 1.0;
+      p[r][0] = lo.x; p[r][1] = lo.y; p[r][2] = hi.x; p[r][3] = hi.y;
+      p[r][r] += 1.0;
     }
-    int bad;
-    spd4_inverse(P4, D, piv, bad);
+    hook(1);
+    // D = P^-1 (4 x 4 SPD, lower triangle read) by LDL'; bad = index + 1 of the first pivot that is
+    // not a positive finite number (what follows a bad pivot is garbage the caller discards: info)
+    int bad = 0;
+    auto fix = [&](double d, int k) {
+      const bool ok = (d > 0.0) && (d < 1.7e308);
+      bad = (!ok && bad == 0) ? k + 1 : bad;
+      return d;
+    };
+    const double d0 = fix(p[0][0], 0);
+    const double r0 = fast_rcp(d0);
+    hook(2);
+    const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
+    const double p11 = fma(-l10, p[1][0], p[1][1]);
+    const double p21 = fma(-l20, p[1][0], p[2][1]);
+    const double p31 = fma(-l30, p[1][0], p[3][1]);
+    double p22 = fma(-l20, p[2][0], p[2][2]);
+    double p32 = fma(-l30, p[2][0], p[3][2]);
+    double p33 = fma(-l30, p[3][0], p[3][3]);
+    hook(3);
+    const double d1 = fix(p11, 1);
+    const double r1 = fast_rcp(d1);
+    hook(4);
+    const double l21 = p21 * r1, l31 = p31 * r1;
+    p22 = fma(-l21, p21, p22);
+    p32 = fma(-l31, p21, p32);
+    p33 = fma(-l31, p31, p33);
+    const double d2 = fix(p22, 2);
+    hook(5);
+    const double r2 = fast_rcp(d2);
+    const double l32 = p32 * r2;
+    p33 = fma(-l32, p32, p33);
+    const double d3 = fix(p33, 3);
+    hook(6);
+    const double r3 = fast_rcp(d3);
+    // M = L^-1 (unit lower)
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -fma(l21, m10, l20);
+    const double m31 = -fma(l32, m21, l31);
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+    hook(7);
+    // D = M' diag(r) M
+    double D[4][4];
+    D[3][3] = r3;
+    D[3][2] = r3 * m32;
+    D[3][1] = r3 * m31;
+    D[3][0] = r3 * m30;
+    D[2][2] = fma(m32, D[3][2], r2);
+    D[2][1] = fma(m32, D[3][1], r2 * m21);
+    D[2][0] = fma(m32, D[3][0], r2 * m20);
+    D[1][1] = fma(m31, D[3][1], fma(m21, r2 * m21, r1));
+    D[1][0] = fma(m31, D[3][0], fma(m21, r2 * m20, r1 * m10));
+    D[0][0] = fma(m30, D[3][0], fma(m20, r2 * m20, fma(m10, r1 * m10, r0)));
+    D[0][1] = D[1][0]; D[0][2] = D[2][0]; D[0][3] = D[3][0];
+    D[1][2] = D[2][1]; D[1][3] = D[3][1]; D[2][3] = D[3][2];
+    hook(8);
     info = (bad != 0 && info == 0) ? 4 * b + bad : info;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    {
       int e;
-      pm *= frexp(piv[k], &e);
-      pe += e;
-    }
-    if ((b & 7) == 7) {  // keep the mantissa product in range
-      int e;
-      pm = frexp(pm, &e);
-      pe += e;
+      pm *= frexp(d0, &e); pe += e;
+      pm *= frexp(d1, &e); pe += e;
+      pm *= frexp(d2, &e); pe += e;
+      pm *= frexp(d3, &e); pe += e;
+      if ((b & 7) == 7) {  // keep the mantissa product in range
+        pm = frexp(pm, &e);
+        pe += e;
+      }
     }
     // evaluate now: otherwise all pivots stay in registers until the end of the sweep
     asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
+    hook(9);
     // this lane's column g of D, picked with 0/1 weights (exact). A select chain here is turned
     // into divergent branches around the whole D computation by hipcc.
     double dc[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h)
       dc[h] = fma(gm[3], D[h][3], fma(gm[2], D[h][2], fma(gm[1], D[h][1], gm[0] * D[h][0])));
-    double nf[NT];
+    hook(10);
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
       const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
@@ -150,12 +162,47 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
       nf[it] = -fma(hi.y, dc[3], fma(hi.x, dc[2], fma(lo.y, dc[1], lo.x * dc[0])));
     }
     __builtin_amdgcn_wave_barrier();  // Pn is rewritten by the next block
+    hook(11);
+  };
+  double bq[NT], nf[NT];
+  serial(0, bq, nf, [](int) {});
 #pragma unroll
-    for (int it = 0; it < NT; ++it)
+  for (int b = 0; b < NK; ++b) {
+    const int it0 = b >> 2, v0 = b & 3;
+    const bool dg = (l == 4 * v0 + g);
+    const int it1 = (b + 1 < NK) ? ((b + 1) >> 2) : it0;  // tile row of the next block's rows
+    // phase A: that tile row first
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
+    for (int jt = 0; jt < NT; ++jt)
+      A[it1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nf[it1], bq[jt], A[it1][jt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase B: the other tile rows, one MFMA per stage of the next block's serial part
+    constexpr int CNT = (NT - 1) * NT;
+    auto issue = [&](int k) {  // pending MFMAs [k CNT / 12, (k + 1) CNT / 12)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < CNT; ++q) {
+        if (q < k * CNT / 12 || q >= (k + 1) * CNT / 12) continue;
+        const int ri = q / NT, jt = q % NT;
+        const int it = ri < it1 ? ri : ri + 1;
         A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nf[it], bq[jt], A[it][jt], 0, 0, 0);
-    A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (b + 1 < NK) {
+      double bq2[NT], nf2[NT];
+      serial(b + 1, bq2, nf2, issue);
+      A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        bq[jt] = bq2[jt];
+        nf[jt] = nf2[jt];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) issue(k);
+      A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+    }
   }
 }
 
