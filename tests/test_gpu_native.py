@@ -422,3 +422,66 @@ def test_common_times_common_hp_inverts_once(m):
     g_o = orc.gr_GP_mod_common_hp(d1["ni"][0], db, mean_db, orc.kernel, (labels, d1["cov"]))
     f_new = orc.logL_GP_mod_common_hp(d1["ni"][0], db, mean_db, orc.kernel, (labels, d1["cov"]))
     assert f_new < f_o and np.abs(g_o).max() < 1e-3 * max(1.0, abs(f_new))
+
+
+def test_failed_estep_factorisation_is_an_error_not_a_silent_nan(m):
+    """a K_0 that is not positive definite in floating point (huge length scale, zero
+    jitter -- pen_diag is the SIGNED mean of sigma_i, CF:381) must surface: e_step reports
+    info != 0 and a NaN f0, the EM drivers stop with LinAlgError (the reference would go on with
+    MASS::ginv of that matrix, CF:387 -- not replicated for the N x N factorisations)."""
+    from magma_amd.native import NativeEngine
+    rng = np.random.default_rng(3)
+    db = _ragged_db(rng, [20] * 6)
+    ds = m.Dataset(db)
+    th0 = np.array([1.0, 9.0])
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+    thi[::2, 2] = -0.2  # mean(sigma_i) = 0, sigma_i^2 > 0
+    nat = NativeEngine(ds)
+    info = nat.e_step(th0, thi, 0.0, 0.0)
+    assert info != 0 and np.isnan(nat.last_f0)
+    with pytest.raises(np.linalg.LinAlgError):
+        nat.em_iteration(th0, thi, 0.0, False)
+    with pytest.raises(np.linalg.LinAlgError):
+        m.Engine(ds).em_iteration(th0, thi, 0.0, False)
+    # the engine is still usable afterwards
+    assert nat.e_step(np.array([1.0, 1.0]), thi, 0.2, 0.0) == 0 and np.isfinite(nat.last_f0)
+    nat.close()
+
+
+def test_prefetched_estep_sums_are_only_taken_for_the_same_hyperparameters(m):
+    """An EM iteration starts the next E-step's sums over individuals under its last monitoring
+    call (driver.hip, prefetch_estep_sums). They must be used only when the next E-step is called
+    with exactly those theta_i, and give the same bits as an E-step that computes them itself."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    rng = np.random.default_rng(5)
+    db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50])
+    ds = m.Dataset(db)
+    th0 = np.array([0.9, 0.7])
+    thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1)) + rng.uniform(-0.2, 0.2, size=(ds.M, 3))
+    res = {}
+    try:
+        for pf in (1, 0):
+            _lib.call("magma_set_option", b"prefetch", pf)
+            eng = NativeEngine(ds)
+            n0, ni, _, _ = eng.em_iteration(th0, thi, 0.3, False)
+            pen = float(np.mean(ni[:, 2]))
+            assert eng.e_step(n0, ni, pen, 0.3) == 0           # the prefetched sums (if any)
+            same = (eng.get_mean(), eng.get_cov())
+            other = ni + 0.01
+            assert eng.e_step(n0, other, pen, 0.3) == 0        # other theta_i: must not be taken
+            n1 = eng.em_iteration(n0, ni, 0.3, False)          # and a following iteration
+            res[pf] = (n0, ni, same, (eng.get_mean(), eng.get_cov()), n1)
+            fresh = NativeEngine(ds)
+            assert fresh.e_step(n0, other, pen, 0.3) == 0
+            eng.e_step(n0, other, pen, 0.3)
+            assert np.array_equal(fresh.get_cov(), eng.get_cov())
+            fresh.close()
+            eng.close()
+    finally:
+        _lib.call("magma_set_option", b"prefetch", 1)
+    a, b = res[1], res[0]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1]) and a[4][2:] == b[4][2:]
