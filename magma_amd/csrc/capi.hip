@@ -95,11 +95,13 @@ static int check_small(int M, int nmax) {
 // products split over ranks by block rows, the two gradient sums all-reduced (driver.h).
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
-                     void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh) {
+                     void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
+                     const double* cov_fac) {
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = ((N + 63) / 64) * 64;
   Work wk(work, Np);
   int rc;
+  if (sh) cov_fac = nullptr;  // (Y Y^T needs every block row of Y: not with sharded rows)
   {
     Prof pf(PROF_COV_GRID, st);
     if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
@@ -115,13 +117,15 @@ int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, do
       Prof pf(PROF_GEMM, st);
       if (sh)
         rc = launch_gemm_nt_rows(Np, Np, Np, wk.A0, Np, cov, Np, wk.T, Np, sh->rank, sh->world, st);
+      else if (cov_fac)
+        rc = launch_gemm_nt_tri(Np, wk.A0, cov_fac, wk.T, st);  // Y = K_0^-1 V^T
       else
         rc = launch_gemm_nt(Np, Np, Np, 1.0, wk.A0, Np, cov, Np, 0.0, wk.T, Np, st);
       if (rc) return rc;
     }
     Prof pf(PROF_CONTRACT, st);
     if ((rc = launch_theta0_contract(N, Np, wk.T, wk.A0, wk.alpha, grid, theta1, theta2, wk.Z,
-                                     wk.partials, nullptr, st, sh)))
+                                     wk.partials, nullptr, st, sh, cov_fac ? wk.T : nullptr)))
       return rc;
   }
   // (f, g1, g2, info) in one device-to-host copy
@@ -137,6 +141,13 @@ int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, do
   h_out3[2] = h4[2];
   if (h_info) *h_info = (int)h4[3];
   return 0;
+}
+
+int estep_cov_factor(int N, void* work, double* V, hipStream_t st) {
+  const int Np = ((N + 63) / 64) * 64;
+  Work wk(work, Np);
+  // both inverse routes keep U = L^-T in the second Np^2 block of their workspace
+  return launch_transpose_upper(Np, wk.inv + (size_t)Np * Np, V, st);
 }
 
 int indiv_dense_eval_impl(int n, const double* grid, const double* th3, const double* yv,
@@ -186,7 +197,7 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
                       const double* mean, const double* m0, const double* cov, int m, double factr,
                       double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,
                       double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
-                      const Theta0Shard* sh) {
+                      const Theta0Shard* sh, const double* cov_fac) {
   if (N < 1) return fail(2, "N must be >= 1");
   if (!h_theta0 || !h_theta_out) return fail(2, "theta0_mstep: NULL argument");
   magma_lbfgsb* opt = magma_lbfgsb_create(1, 2, h_theta0, m, factr, pgtol, maxit);
@@ -201,7 +212,7 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
     double out3[3] = {0.0, 0.0, 0.0};
     int info = 0;
     if ((rc = theta0_eval_impl(N, grid, x[0], x[1], pen_diag, mean, m0, cov, 1, work, out3, &info, st,
-                               sh)))
+                               sh, cov_fac)))
       break;
     const double f = (info == 0) ? out3[0] : __builtin_nan("");  // not SPD: as a failed evaluation
     if (first && h_f_x0) *h_f_x0 = f;
@@ -560,6 +571,10 @@ int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, co
 
 int magma_set_option(const char* name, long value) {
   if (!name) return fail(2, "option name is NULL");
+  if (std::string(name) == "cov_factor") {  // theta_0 gradient through the E-step's factor of cov
+    set_covfac(value != 0);
+    return 0;
+  }
   if (std::string(name) == "prefetch") {  // next E-step's sums started under the monitoring call
     set_prefetch(value != 0);
     return 0;

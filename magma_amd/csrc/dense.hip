@@ -475,15 +475,20 @@ __global__ __launch_bounds__(256, 8) void gemm_nt_kernel(int K, double alpha,
                                                       const double* __restrict__ A, int64_t lda,
                                                       const double* __restrict__ B, int64_t ldb,
                                                       double beta, double* __restrict__ C,
-                                                      int64_t ldc, int row0, int rstride) {
+                                                      int64_t ldc, int row0, int rstride,
+                                                      int ktri) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   TileAcc acc;
   tile_zero(acc);
   // block row of this workgroup: all of them (row0 = 0, rstride = 1) or one rank's share
   const int64_t bi = row0 + (int64_t)rstride * blockIdx.x;
-  tile_gemm_nt(A + bi * NB, lda, B + (int64_t)blockIdx.y * NB, ldb, K / 16, acc, As, Bs);
-  double* Ct = C + bi * NB + (int64_t)blockIdx.y * NB * ldc;
+  // ktri: B is lower triangular (B(n, k) = 0 for k > n): column tile bj sums k < 64 (bj + 1) only;
+  // the column tiles are then handed out longest first
+  const int bj = ktri ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  const int kend = ktri ? min(K, NB * (bj + 1)) : K;
+  tile_gemm_nt(A + bi * NB, lda, B + (int64_t)bj * NB, ldb, kend / 16, acc, As, Bs);
+  double* Ct = C + bi * NB + (int64_t)bj * NB * ldc;
   if (beta == 0.0) {
     tile_foreach(acc, [&](int m, int n, double v) { Ct[m + (int64_t)n * ldc] = alpha * v; });
   } else {
@@ -943,8 +948,41 @@ int launch_gemm_nt(int Mr, int Nc, int K, double alpha, const double* A, int64_t
                    hipStream_t st) {
   if (Mr % 64 || Nc % 64 || K % 16) return fail(2, "gemm_nt: dimensions must be padded (64/64/16)");
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(Mr / 64, Nc / 64), dim3(256), 0, st, K, alpha, A, lda, B,
-                     ldb, beta, C, ldc, 0, 1);
+                     ldb, beta, C, ldc, 0, 1, 0);
   return check_hip(hipGetLastError(), "gemm_nt");
+}
+
+// C = A B^T with B lower triangular (its tiles above the diagonal are never read): half the work.
+int launch_gemm_nt_tri(int Np, const double* A, const double* B, double* C, hipStream_t st) {
+  if (Np % 64) return fail(2, "gemm_nt_tri: dimension must be padded to 64");
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, st, Np, 1.0, A,
+                     (int64_t)Np, B, (int64_t)Np, 0.0, C, (int64_t)Np, 0, 1, 1);
+  return check_hip(hipGetLastError(), "gemm_nt_tri");
+}
+
+// V = U^T for the upper triangular U (tiles on or above the diagonal; V's tiles above the
+// diagonal are left alone): V(n, k) = U(k, n), 64 x 64 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_upper_kernel(int nt, const double* __restrict__ U,
+                                                              double* __restrict__ V, int64_t ld) {
+  __shared__ double Ts[64 * 65];
+  const int p = blockIdx.x;  // lower tile (n >= k) of V
+  int n = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (n * (n + 1) / 2 > p) --n;
+  while ((n + 1) * (n + 2) / 2 <= p) ++n;
+  const int k = p - n * (n + 1) / 2;
+  const double* Ut = U + (int64_t)k * NB + (int64_t)n * NB * ld;
+  double* Vt = V + (int64_t)n * NB + (int64_t)k * NB * ld;
+  const int r = threadIdx.x & 63, c0 = threadIdx.x >> 6;
+  for (int c = c0; c < 64; c += 4) Ts[c * 65 + r] = Ut[r + (int64_t)c * ld];  // Ts[c][r] = U(r, c)
+  __syncthreads();
+  for (int c = c0; c < 64; c += 4) Vt[r + (int64_t)c * ld] = Ts[r * 65 + c];  // V(r, c) = U(c, r)
+}
+
+int launch_transpose_upper(int Np, const double* U, double* V, hipStream_t st) {
+  const int nt = Np / NB;
+  hipLaunchKernelGGL(transpose_upper_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nt, U, V,
+                     (int64_t)Np);
+  return check_hip(hipGetLastError(), "transpose_upper");
 }
 
 // The block rows rank, rank + world, ... of C = A B^T only (sharded theta_0 gradient).
@@ -955,7 +993,7 @@ int launch_gemm_nt_rows(int Mr, int Nc, int K, const double* A, int64_t lda, con
   const int rows = rank < nt ? (nt - rank + world - 1) / world : 0;
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(rows, Nc / 64), dim3(256), 0, st, K, 1.0, A, lda, B, ldb, 0.0,
-                     C, ldc, rank, world);
+                     C, ldc, rank, world, 0);
   return check_hip(hipGetLastError(), "gemm_nt_rows");
 }
 
@@ -1019,14 +1057,15 @@ int theta0_contract_slices(int Np) {
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
                            double* Z, double* partials, double* out2, hipStream_t st,
-                           const Theta0Shard* sh) {
+                           const Theta0Shard* sh, const double* Bprod) {
+  if (Bprod == nullptr) Bprod = Kinv;  // Z = T Bprod^T on the lower tiles
   const int nt = Np / NB;
   const int ks = theta0_contract_slices(Np);
   const int64_t n2 = (int64_t)Np * Np;
   const int ntiles = sh ? sh->nplist : nt * (nt + 1) / 2;
   if (ntiles > 0)
     hipLaunchKernelGGL(gemm_nt_lower_kernel, dim3(ntiles * ks), dim3(256), 0, st, Np, T, (int64_t)Np,
-                       Kinv, (int64_t)Np, Z, (int64_t)Np, n2, ks, sh ? sh->plist : nullptr);
+                       Bprod, (int64_t)Np, Z, (int64_t)Np, n2, ks, sh ? sh->plist : nullptr);
   hipLaunchKernelGGL(theta0_contract_kernel, dim3(nt, nt), dim3(256), 0, st, N, Np, Z, ks, n2, Kinv,
                      alpha, grid, th1, th2, partials, sh ? sh->rank : 0, sh ? sh->world : 1);
   if (out2 != nullptr)  // (nullptr: the caller sums the per-tile pairs itself)

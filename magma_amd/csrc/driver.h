@@ -19,12 +19,19 @@ struct Theta0Shard {
 
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
-                     void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh);
+                     void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
+                     const double* cov_fac = nullptr);
 int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double pen_diag,
                       const double* mean, const double* m0, const double* cov, int m, double factr,
                       double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,
                       double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
-                      const Theta0Shard* sh);
+                      const Theta0Shard* sh, const double* cov_fac = nullptr);
+// cov_fac (optional, one rank only): V = L^-1 of the precision the E-step just inverted, lower
+// triangular, cov = V^T V (estep_cov_factor below). The gradient's K_0^-1 cov K_0^-1 is then
+// Y Y^T with Y = K_0^-1 V^T -- a triangular product (N^3) and the lower tiles of a symmetric one
+// (N^3) instead of a full product (2 N^3) and the lower tiles (N^3).
+// After magma_estep_finish on `work`: V <- U^T, U = L^-T as left in the workspace by the inverse.
+int estep_cov_factor(int N, void* work, double* V, hipStream_t st);
 
 // logL_GP_mod + gr_GP_mod (CF:181-201, 304-332) of ONE individual with more observations than a
 // wavefront handles (n > 64), on the dense kernels: the theta_0 evaluation chain on the
@@ -49,6 +56,8 @@ bool dedup_enabled();
 void set_dedup(bool on);
 bool prefetch_enabled();
 void set_prefetch(bool on);
+bool covfac_enabled();
+void set_covfac(bool on);
 
 // out4 = (sum f, sum g[:,0], sum g[:,1], sum g[:,2]) over M entries, fixed order (g may be null)
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st);

@@ -149,6 +149,8 @@ struct magma_dataset {
   // the NEXT E-step's sums over individuals (they depend on theta_i only), started on the side
   // stream next to the monitoring call that ends an EM iteration (prefetch_estep_sums)
   DevBuf P2, w2, theta2, info2, f2;
+  DevBuf covfac;  // V = L^-1 of the last E-step's precision (cov = V^T V); see driver.h
+  bool covfac_ok = false;
   hipEvent_t pre_ev = nullptr;
   bool pre_valid = false, pre_issued = false;
   std::vector<double> pre_theta;
@@ -631,6 +633,7 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
     return rc;
   if (M > 0) {
     if ((rc = d->P2.alloc(sizeof(double) * Np * Np)) || (rc = d->w2.alloc(sizeof(double) * Np)) ||
+        (rc = d->covfac.alloc(sizeof(double) * Np * Np)) ||
         (rc = d->theta2.alloc(sizeof(double) * 3 * Mb)) || (rc = d->info2.alloc(sizeof(int) * Mb)) ||
         (rc = d->f2.alloc(sizeof(double) * Mb)))
       return rc;
@@ -729,6 +732,7 @@ int magma_set_mean_cov(magma_ctx* c, magma_dataset* d, const double* h_mean, con
                                    (size_t)d->N * sizeof(double), (size_t)d->N, hipMemcpyHostToDevice, st));
   d->cpack_ok = false;
   d->dedup_ok = false;
+  d->covfac_ok = false;
   return sync(st);
 }
 
@@ -825,6 +829,11 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   d->a0_key[1] = h_theta0[1];
   d->a0_key[2] = pen_diag;
   d->last_f0 = f0;
+  d->covfac_ok = false;
+  if (info == 0 && !c->has_comm() && d->covfac.p && covfac_enabled()) {
+    if ((rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
+    d->covfac_ok = true;
+  }
   if (d->M > 0) {  // individuals whose K_i was not positive definite (they contributed nothing)
     std::vector<int> hi((size_t)d->M);
     MAGMA_CHECK_HIP(hipMemcpyAsync(hi.data(), d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
@@ -882,7 +891,8 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     rc0 = theta0_mstep_impl(d->N, d->grid.as<double>(), h_theta0, pen, d->mean.as<double>(),
                             d->m0.as<double>(), d->P.as<double>(), o.m, o.factr, o.pgtol, o.maxit,
                             d->work.p, th0_new, nullptr, nullptr, nullptr, &nfev0, nullptr, c->side,
-                            c->has_comm() ? &sh : nullptr);
+                            c->has_comm() ? &sh : nullptr,
+                            d->covfac_ok ? d->covfac.as<double>() : nullptr);
     if (rc0) err0 = magma_last_error();
   };
   // theta_0 and the theta_i problems overlap only when neither side needs the communicator at

@@ -77,7 +77,9 @@ int launch_gemm_nt_rows(int Mr, int Nc, int K, const double* A, int64_t lda, con
 int launch_theta0_contract(int N, int Np, const double* T, const double* Kinv,
                            const double* alpha, const double* grid, double th1, double th2,
                            double* Z, double* partials, double* out2, hipStream_t st,
-                           const Theta0Shard* sh = nullptr);
+                           const Theta0Shard* sh = nullptr, const double* Bprod = nullptr);
+int launch_gemm_nt_tri(int Np, const double* A, const double* B, double* C, hipStream_t st);
+int launch_transpose_upper(int Np, const double* U, double* V, hipStream_t st);
 int theta0_vec_blocks(int Np);
 int launch_theta0_vec(int N, int Np, const double* Kinv, const double* cov, const double* mean,
                       const double* m0, double* alpha, double* vpart, hipStream_t st);

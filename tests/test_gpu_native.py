@@ -115,10 +115,13 @@ def test_native_training_individual_hp_equals_python_engine(m):
     a = nat.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_n)
     b = py.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_p)
     assert a[2] == b[2] and len(t_n) == len(t_p)
-    # (last-bit differences of the host sums, amplified over ~6 EM iterations of 20 optimisations)
-    assert np.abs(a[0] - b[0]).max() < 1e-6 and np.abs(a[1] - b[1]).max() < 1e-4
-    for x, y in zip(t_n, t_p):
-        assert abs(x["logLL"] - y["logLL"]) <= 1e-9 * abs(y["logLL"])
+    # (last-bit differences of the host sums, and the theta_0 gradient formed through the factor
+    # of cov in the driver but through the full product in the Python engine, amplified over ~6 EM
+    # iterations of optimisations that stop at factr = 1e7)
+    assert np.abs(a[0] - b[0]).max() < 1e-5 and np.abs(a[1] - b[1]).max() < 1e-4
+    assert abs(t_n[0]["logLL"] - t_p[0]["logLL"]) <= 1e-9 * abs(t_p[0]["logLL"])
+    for x, y in zip(t_n, t_p):  # (later iterations start from hyper-parameters that differ by ~1e-6)
+        assert abs(x["logLL"] - y["logLL"]) <= 1e-6 * abs(y["logLL"])
     ref = hp_of("hp_FF", 1)  # at optimiser tolerance (see test_gpu_kat)
     assert np.abs(a[0] - ref["theta_0"]).max() < 1e-3
     nat.close()
@@ -485,3 +488,28 @@ def test_prefetched_estep_sums_are_only_taken_for_the_same_hyperparameters(m):
     for x, y in zip(a[2] + a[3], b[2] + b[3]):
         assert np.array_equal(x, y)
     assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1]) and a[4][2:] == b[4][2:]
+
+
+def test_theta0_gradient_through_the_covariance_factor(m):
+    """The driver forms K_0^-1 cov K_0^-1 of the theta_0 gradient (CF:304-332) as Y Y' with
+    Y = K_0^-1 V', cov = V'V the factor the E-step's inverse leaves behind (N^3 less work than
+    through the full product K_0^-1 cov). Same M-step as with the option off, on several tiles."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(400, 25, 500, seed=77)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    th0 = np.array([0.8, 0.9])
+    thi = np.tile([1.0, 1.0, 0.3], (ds.M, 1))
+    out = {}
+    try:
+        for on in (1, 0):
+            _lib.call("magma_set_option", b"cov_factor", on)
+            eng = NativeEngine(ds)
+            assert eng.e_step(th0, thi, 0.3, 0.0) == 0
+            out[on] = eng.m_step(th0, thi, False, {"maxit": 4})
+            eng.close()
+    finally:
+        _lib.call("magma_set_option", b"cov_factor", 1)
+    assert np.abs(out[1][0] - out[0][0]).max() < 1e-8, (out[1][0], out[0][0])
+    assert np.array_equal(out[1][1], out[0][1])  # (the theta_i problems do not see the option)
