@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <map>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -158,13 +160,38 @@ struct magma_dataset {
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
   double a0_key[3] = {0, 0, 0};
-  std::vector<int> last_nfev;
+  std::vector<int> h_perm;
+  DevBuf order;
   // by-products of the last E-step / M-step (logL_monitoring shortcuts, MG:54,60)
   double last_f0 = 0.0, last_sum_fi = 0.0, last_sum_fi_new = 0.0;
   magma_em_stats stats = {0, 0, 0, 0, 0};
 };
 
 namespace {
+
+// Host-side phase timing of the driver (MAGMA_HOST_TIMING=1: printed when a context is destroyed).
+struct HostTiming {
+  bool on = getenv("MAGMA_HOST_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  std::map<std::string, std::pair<long, double>> acc;
+  void mark(const char* label) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    auto& a = acc[label];
+    a.first += 1;
+    a.second += std::chrono::duration<double, std::micro>(now - last).count();
+    last = now;
+  }
+  void dump() {
+    if (!on) return;
+    for (auto& kv : acc)
+      fprintf(stderr, "[magma host timing] %-28s n=%6ld  avg %9.1f us  total %10.1f ms\n",
+              kv.first.c_str(), kv.second.first, kv.second.second / kv.second.first, kv.second.second * 1e-3);
+    acc.clear();
+  }
+};
+HostTiming g_ht;
+#define HT(label) g_ht.mark(label)
 
 struct Opt {
   int m = 5, maxit = 100;
@@ -513,6 +540,7 @@ int magma_ctx_create_callback(magma_ctx** out, int device, int rank, int world,
 }
 
 void magma_ctx_destroy(magma_ctx* c) {
+  g_ht.dump();
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->comm && rccl().ok) (void)rccl().destroy(c->comm);
@@ -622,7 +650,7 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
       (rc = d->v.alloc(sizeof(double) * (size_t)std::max<int64_t>(R, 1))) ||
       (rc = d->theta.alloc(sizeof(double) * 3 * Mb)) || (rc = d->f.alloc(sizeof(double) * Mb)) ||
       (rc = d->g.alloc(sizeof(double) * 3 * Mb)) || (rc = d->info.alloc(sizeof(int) * Mb)) ||
-      (rc = d->sel.alloc(sizeof(int) * Mb)) || (rc = d->fsum.alloc(sizeof(double) * 16)) ||
+      (rc = d->sel.alloc(sizeof(int) * Mb)) || (rc = d->order.alloc(sizeof(int) * Mb)) || (rc = d->fsum.alloc(sizeof(double) * 16)) ||
       (rc = d->P.alloc(sizeof(double) * Np * Np)) || (rc = d->w.alloc(sizeof(double) * Np)) ||
       (rc = d->mean.alloc(sizeof(double) * Np)) || (rc = d->m0.alloc(sizeof(double) * Np)) ||
       (rc = d->work.alloc(magma_workspace_bytes(N))) ||
@@ -758,8 +786,11 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   if (int rc = set_device(c)) return rc;
   hipStream_t st = c->main;
   int rc;
+  HT("(between calls)");
   if ((rc = set_m0(d, h_m0, n_m0, st))) return rc;
+  HT("e: set_m0");
   if ((rc = set_theta(d, h_theta_i, theta_stride, st))) return rc;
+  HT("e: set_theta");
   d->cpack_ok = false;
   d->dedup_ok = false;
   const size_t Np = (size_t)d->Np;
@@ -816,6 +847,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if ((rc = launch_pack_lower(d->Np, d->P.as<double>(), d->pack.as<double>(), 1, st))) return rc;
     if ((rc = c->allreduce(d->w.as<double>(), d->Np, st))) return rc;
   }
+  HT("e: sums launched");
   const int reuse = d->a0_valid && d->a0_key[0] == h_theta0[0] && d->a0_key[1] == h_theta0[1] &&
                     d->a0_key[2] == pen_diag;
   int info = 0;
@@ -824,6 +856,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                d->m0.as<double>(), d->P.as<double>(), d->w.as<double>(),
                                d->mean.as<double>(), d->work.p, reuse, &f0, &info, st)))
     return rc;
+  HT("e: finish (sync)");
   d->a0_valid = (info == 0);
   d->a0_key[0] = h_theta0[0];
   d->a0_key[1] = h_theta0[1];
@@ -842,6 +875,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   }
   if (h_info) *h_info = info;
   if (h_f0) *h_f0 = f0;
+  HT("e: factor + flagged (sync)");
   return 0;
 }
 
@@ -898,6 +932,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   // theta_0 and the theta_i problems overlap only when neither side needs the communicator at
   // the same time: individual hyper-parameters (the theta_i problems exchange nothing until the
   // end), or a single rank
+  HT("m: entry");
   const bool overlap = !common_hp || !c->has_comm();
   std::thread th0;
   if (overlap) {
@@ -952,20 +987,15 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     std::vector<int> hnf((size_t)std::max<int64_t>(M, 1));
     if (M > 0) {
       do {
+        HT("m: sync + thread start");
         if ((rc = ensure_cpack(d, st))) break;
         if ((rc = set_theta(d, h_theta_i, 3, st))) break;
+        HT("m: cpack + theta");
         const int* order = nullptr;
-        if (d->have_order && (int64_t)d->last_nfev.size() == M) {
-          // longest chains of the previous call first (they tend to stay the longest)
-          std::vector<int> perm((size_t)M);
-          std::iota(perm.begin(), perm.end(), 0);
-          std::stable_sort(perm.begin(), perm.end(),
-                           [&](int a, int b) { return d->last_nfev[(size_t)a] > d->last_nfev[(size_t)b]; });
-          if ((rc = check_hip(hipMemcpy(d->sel.p, perm.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice),
-                              "m_step order")))
-            break;
-          order = d->sel.as<int>();
-        }
+        // longest chains of the previous call first (they tend to stay the longest); the
+        // permutation was uploaded at the end of that call
+        if (d->have_order) order = d->order.as<int>();
+        HT("m: order");
         if ((rc = magma_indiv_mstep_resident(0, (int)M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
                                              d->y.as<double>(), d->idx.as<int>(), d->mean.as<double>(),
                                              d->cpack.as<double>(), d->theta.as<double>(), order, o.m,
@@ -978,8 +1008,18 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
             (rc = d2h(hfx0.data(), d->rfx0.p, sizeof(double) * (size_t)M, st)) ||
             (rc = d2h(hnf.data(), d->rnf.p, sizeof(int) * (size_t)M, st)) || (rc = sync(st)))
           break;
-        d->last_nfev = hnf;
-        d->have_order = true;
+        HT("m: resident (launch + d2h sync)");
+        {  // next call's order: by evaluation count, descending, stable (counting sort)
+          int top = 0;
+          for (int64_t i = 0; i < M; ++i) top = std::max(top, hnf[(size_t)i]);
+          std::vector<int> pos((size_t)top + 2, 0);
+          for (int64_t i = 0; i < M; ++i) ++pos[(size_t)(top - hnf[(size_t)i]) + 1];
+          for (size_t q = 1; q < pos.size(); ++q) pos[q] += pos[q - 1];
+          d->h_perm.resize((size_t)M);
+          for (int64_t i = 0; i < M; ++i) d->h_perm[(size_t)pos[(size_t)(top - hnf[(size_t)i])]++] = (int)i;
+          if ((rc = h2d(d->order.p, d->h_perm.data(), sizeof(int) * (size_t)M, st))) break;
+          d->have_order = true;
+        }
         int mx = 0;
         for (int64_t i = 0; i < M; ++i) {
           sums[0] += hfx0[(size_t)i];
@@ -1019,8 +1059,10 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
       magma_lbfgsb_destroy(lb);
       sums[1] += fb;
     }
+    HT("m: host sums");
     // the theta_0 thread may still be using the communicator: wait for it before this thread does
     if (int r2 = join0()) rc = rc ? rc : r2;
+    HT("m: join theta_0");
     if (!rc && c->has_comm()) {
       double* gb = d->gath.as<double>();
       rc = check_hip(hipMemsetAsync(gb, 0, sizeof(double) * 3 * (size_t)Mt, st), "m_step gather");
@@ -1042,6 +1084,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   d->last_sum_fi_new = sums[1];
   h_theta0_out[0] = th0_new[0];
   h_theta0_out[1] = th0_new[1];
+  HT("m: tail");
   return 0;
 }
 
@@ -1070,11 +1113,14 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   // first evaluations. logL_monitoring(new hp) (MG:60): individual terms = the optimisers' final
   // values; only the theta_0 term needs an evaluation, which leaves K_0^-1 for the next E-step.
   h_logl2[0] = -d->last_f0 - d->last_sum_fi;
+  HT("em: nan scan");
   if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) return rc;
+  HT("em: prefetch launch");
   const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
   double ll0 = 0.0;
   if (int rc = theta0_f(c, d, h_theta0_out, sig, &ll0)) return rc;
   h_logl2[1] = -ll0 - d->last_sum_fi_new;
+  HT("em: monitoring (sync)");
   return 0;
 }
 

@@ -23,6 +23,22 @@ python3 $root/profiles/pmc_summary.py $out/pmc_c3_${steps}_${warm}.json FETCH_SI
   SQ_INSTS_VALU_MFMA_MOPS_F64=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 \
   SQ_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+# compact per-launch timeline (start us, duration us, stream, short kernel name) of the traced run
+python3 - $out <<'PYEOF'
+import csv, glob, sys
+out = sys.argv[1]
+files = glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True)
+if files:
+    rows = list(csv.DictReader(open(files[0])))
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    with open(out + "/timeline_compact.csv", "w") as fh:
+        fh.write("start_us,dur_us,stream,kernel\n")
+        for r in rows:
+            name = r["Kernel_Name"].replace("magma::", "").split("(")[0][:48]
+            fh.write("%.1f,%.1f,%s,%s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
+                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Stream_Id", ""), name))
+PYEOF
 # keep the merge small: the raw traces stay on the box
 find $out -name "*.csv" -size +1M -delete
 find $out -name "*.db" -delete
