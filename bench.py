@@ -159,6 +159,9 @@ def main():
     lib = _lib.load()
     if os.environ.get("MAGMA_DEDUP", "1") == "0":  # C2: batched sum instead of one inverse per evaluation
         _lib.call("magma_set_option", b"dedup", 0)
+    for kv in filter(None, os.environ.get("MAGMA_OPTIONS", "").split(",")):  # e.g. "dag_walker=0,prefetch=0"
+        name, val = kv.split("=")
+        _lib.call("magma_set_option", name.strip().encode(), int(val))
 
     cfg = dict(CONFIGS[args.config])
     if args.config == "c5" and args.scaling == "strong":

@@ -592,6 +592,10 @@ int magma_set_option(const char* name, long value) {
     set_dag_workgroups((int)value);
     return 0;
   }
+  if (std::string(name) == "dag_walker") {  // one workgroup walks the chain of diagonal tiles
+    set_dag_walker((int)value);
+    return 0;
+  }
   if (std::string(name) == "dag_stamps") {  // device buffer of 8 int64 per ticket; diagnostic builds
     set_dag_stamps(reinterpret_cast<void*>(value));
     return 0;

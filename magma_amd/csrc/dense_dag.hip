@@ -36,6 +36,7 @@
 namespace magma {
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 #define MAGMA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -50,6 +51,8 @@ struct DagArgs {
   int* fL;     // nt x nt flags, [i * nt + k]: tile (i, k) of L published (k == i: X_ii and U_ii)
   int* fU;     // nt x nt flags, [c * nt + k]: tile (c, k) of U published (k == c: same as fL)
   int* ctrl;   // [0] ticket counter, [1] abort word
+  int* fH;     // nt flags (walker mode): S~_jj and B_j of block step j parked in L(j,j) / L(j,j-1)
+  int walker;  // 1: workgroup 0 walks the chain of diagonal tiles (see dag_walker)
   double* logdet;
   int* info;
   long long* stamps;  // diagnostic (MAGMA_DAG_STAMPS builds): 8 wall-clock stamps per ticket
@@ -276,6 +279,7 @@ __device__ __forceinline__ void abandon(int* info) {
   if (threadIdx.x == 0) __hip_atomic_store(info, -999, MAGMA_RLX_AGENT);
 }
 
+
 #ifdef MAGMA_DAG_STAMPS
 #define DAG_STAMP(t, s)                                                          \
   do {                                                                           \
@@ -285,10 +289,201 @@ __device__ __forceinline__ void abandon(int* info) {
 #define DAG_STAMP(t, s) do { } while (0)
 #endif
 
+// The two tiles block step j of the walker needs (see dag_walker), requested by NTHR threads
+// (q = index of this thread among them): 16-byte unit u = q + i NTHR of a tile = rows m2, m2 + 1
+// of column n, m2 = 2 (u & 31), n = u >> 5.
+template <int NTHR>
+__device__ __forceinline__ void walker_fetch(int q, int j, rsrc_t rL, int ld,
+                                             v4u (&tS)[2048 / NTHR], v4u (&tB)[2048 / NTHR]) {
+  const unsigned offD = (unsigned)j * NB * (unsigned)(ld + 1);
+  const unsigned offB = (unsigned)j * NB + (unsigned)(j > 0 ? j - 1 : 0) * NB * (unsigned)ld;
+#pragma unroll
+  for (int i = 0; i < 2048 / NTHR; ++i) {
+    const int u = q + i * NTHR;
+    const unsigned e = (unsigned)((u & 31) * 2) + (unsigned)(u >> 5) * (unsigned)ld;
+    tS[i] = __builtin_amdgcn_raw_buffer_load_b128(rL, (offD + e) * 8u, 0, AUX_SC1);
+    if (j > 0) tB[i] = __builtin_amdgcn_raw_buffer_load_b128(rL, (offB + e) * 8u, 0, AUX_SC1);
+  }
+}
+
+// ... and parked in LDS: B_j as Ws[k * TLD + m] (operand layout), S~_jj as Ss[m * 65 + n].
+template <int NTHR>
+__device__ __forceinline__ void walker_park(int q, int j, const v4u (&tS)[2048 / NTHR],
+                                            const v4u (&tB)[2048 / NTHR], double* Ws, double* Ss) {
+#pragma unroll
+  for (int i = 0; i < 2048 / NTHR; ++i) {
+    const int u = q + i * NTHR;
+    const int m2 = (u & 31) * 2, n = u >> 5;
+    double2 pr;
+    __builtin_memcpy(&pr, &tS[i], 16);
+    Ss[m2 * 65 + n] = pr.x;
+    Ss[(m2 + 1) * 65 + n] = pr.y;
+    if (j > 0) *reinterpret_cast<v4u*>(&Ws[n * TLD + m2]) = tB[i];
+  }
+}
+
+// The chain of diagonal tiles walked by ONE workgroup (workgroup 0, outside the ticket order).
+// With a task per block step (D(j) below) every step pays: X_{j-1,j-1} stored, drained, flagged,
+// polled by the next step's workgroup and fetched back from L2 -- 3-4 of the 21 us a step takes.
+// Here X stays in LDS from one step to the next. What a step needs from the rest of the graph,
+//   S~_jj = A_jj - sum_{k<j-1} L_jk L_jk^T   and   B_j = A_{j,j-1} - sum_{k<j-1} L_jk L_{j-1,k}^T,
+// is accumulated by the ticket task H(j) (the slot D(j) had), parked in the tiles L(j,j) /
+// L(j,j-1) (nobody reads those before their flags go up) and announced through fH[j]. H(j + 1)
+// gets its last term (L_{j,j-1}) early in step j and finishes under the factorisation of step j,
+// during which the two wavefronts that have no part in it fetch its tiles into LDS. Step j:
+//   L_{j,j-1} = B_j X_{j-1,j-1}^T (both in LDS) -> S = S~ - L L^T -> 64 x 64 factor -> X_jj, U_jj.
+// The walker holds no ticket and waits only for H tasks; a worker only ever waits for earlier
+// tickets or for the walker, so with one worker resident the graph drains.
+__device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t rU, double* Vs,
+                                           double* Ws, double* Ss, double* Pn, double* Xch,
+                                           int* s_ready, int* s_walk) {
+  const int nt = a.nt, ld = a.ld;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int l = lane & 15, g = lane >> 4;
+  const int fo = (lane >> 4) * TLD + (lane & 15);
+  const int m2 = (tid & 31) * 2;
+  {  // step 0's tile, by everybody
+    if (poll_ready(a.fH, a.fH, 0, 1, a.ctrl, s_ready) < 0) return abandon(a.info);
+    v4u tS[8], tB[8];
+    walker_fetch<256>(tid, 0, rL, ld, tS, tB);
+    walker_park<256>(tid, 0, tS, tB, Ws, Ss);
+    __syncthreads();
+  }
+  for (int j = 0; j < nt; ++j) {
+    const unsigned offD = (unsigned)j * NB * (unsigned)(ld + 1);
+    const unsigned offB = (unsigned)j * NB + (unsigned)(j > 0 ? j - 1 : 0) * NB * (unsigned)ld;
+    const int ts = nt * nt + nt * (nt + 1) / 2 + j;  // (diagnostic stamps: slots behind the tickets')
+    (void)ts;
+    DAG_STAMP(ts, 0);
+    TileAcc acc;
+    tile_zero(acc);
+    if (j > 0) {
+      // B_j is in Ws[k * TLD + m], X_{j-1,j-1} in Vs[k * TLD + n] = X(n, k) since the last step
+      TileAcc out;
+      tile_zero(out);
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 4) {
+        const double fa0 = Ws[kk * TLD + fo + wm * 32];
+        const double fa1 = Ws[kk * TLD + fo + wm * 32 + 16];
+        const double fb0 = Vs[kk * TLD + fo + wn * 32];
+        const double fb1 = Vs[kk * TLD + fo + wn * 32 + 16];
+        out.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, out.c[0][0], 0, 0, 0);
+        out.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, out.c[0][1], 0, 0, 0);
+        out.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, out.c[1][0], 0, 0, 0);
+        out.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, out.c[1][1], 0, 0, 0);
+      }
+      __syncthreads();  // every wavefront has read Ws and Vs
+      DAG_STAMP(ts, 1);
+      tile_foreach(out, [&](int m, int n, double v) { Ws[n * TLD + m] = v; });  // L_{j,j-1}
+      __syncthreads();
+      store_tile_sc1(Ws, rL, offB, ld);
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 4) {  // acc = L L^T
+        const double fa0 = Ws[kk * TLD + fo + wm * 32];
+        const double fa1 = Ws[kk * TLD + fo + wm * 32 + 16];
+        const double fb0 = Ws[kk * TLD + fo + wn * 32];
+        const double fb1 = Ws[kk * TLD + fo + wn * 32 + 16];
+        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
+        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
+        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
+      }
+    }
+    // S = S~ - L L^T staged for the factor as Vs[m * 65 + n] (X of the last step is dead: every
+    // wavefront passed the barrier after the product)
+    tile_foreach(acc, [&](int m, int n, double v) { Vs[m * 65 + n] = Ss[m * 65 + n] - v; });
+    // L_{j,j-1}'s flag: its stores have drained under the product above
+    if (j > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j > 0 && tid == 0) __hip_atomic_store(a.fL + j * nt + (j - 1), 1, MAGMA_RLX_AGENT);
+    DAG_STAMP(ts, 2);
+    if (wave == 0) {
+      v4d S[4][4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
+            S[it][jt][v] = (rr >= cc) ? Vs[rr * 65 + cc] : Vs[cc * 65 + rr];
+          }
+      double pm = 1.0;
+      int pe = 0, bad = 0;
+      chol64_factor(S, Pn, Xch, lane, pm, pe, bad);
+      if (lane == 0) {
+        atomicAdd(a.logdet, log(pm) + (double)pe * 0.69314718055994530941723212145818);
+        if (bad != 0) atomicCAS(a.info, 0, j * NB + bad);
+      }
+      __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
+    } else if (wave == 1) {
+      v4d B[4][4];
+      chol64_solve(B, Pn + 256, Xch, lane);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
+            const double x = (jt <= it) ? B[it][jt][v] : 0.0;  // X(rr, cc)
+            Vs[cc * TLD + rr] = x;                              // column cc of X
+            // U_jj = X_jj^T straight from the registers: U(cc, rr), 16 lanes = 128 contiguous bytes
+            // (a transposed read of Vs would be a 16-way bank conflict at this row length)
+            v2u xv;
+            __builtin_memcpy(&xv, &x, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(
+                xv, rU, (offD + (unsigned)cc + (unsigned)rr * (unsigned)ld) * 8u, 0, AUX_SC1);
+          }
+    } else {
+      // the two wavefronts with no part in the factorisation: the coming step's tiles. H(j + 1)
+      // normally finishes a few microseconds into this step's factorisation: its flag is looked at
+      // once per barrier from the 7th on -- never waited for here: with few workgroups H(j + 1)'s
+      // ticket may still be behind tasks that wait for this very X_jj.
+      v4u tS[16], tB[16];
+      bool issued = false;
+#pragma unroll 1
+      for (int b = 0; b < 16; ++b) {
+        if (b >= 6 && !issued && j + 1 < nt &&
+            __hip_atomic_load(a.fH + j + 1, MAGMA_RLX_AGENT) != 0) {
+          walker_fetch<128>(tid - 128, j + 1, rL, ld, tS, tB);
+          issued = true;
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+      if (issued) walker_park<128>(tid - 128, j + 1, tS, tB, Ws, Ss);
+      if (lane == 0) s_walk[wave - 2] = issued ? 1 : 0;
+    }
+    __syncthreads();
+    const bool parked = (s_walk[0] != 0) && (s_walk[1] != 0);
+    DAG_STAMP(ts, 3);
+    // X_jj (it overwrites the parked S~_jj, which this workgroup has consumed) and U_jj = X_jj^T
+    store_tile_sc1(Vs, rL, offD, ld);
+    DAG_STAMP(ts, 4);
+    publish(a.fL + j * nt + j, a.fU + j * nt + j);
+    DAG_STAMP(ts, 5);
+    if (j + 1 < nt && !parked) {  // (X_jj is out: whatever H(j + 1) still waits for can now finish)
+      if (tid == 0) atomicAdd(a.ctrl + 2, 1);  // diagnostic: steps whose tiles came late
+      if (poll_ready(a.fH + j + 1, a.fH + j + 1, 0, 1, a.ctrl, s_ready) < 0) return abandon(a.info);
+      v4u tS[8], tB[8];
+      walker_fetch<256>(tid, j + 1, rL, ld, tS, tB);
+      walker_park<256>(tid, j + 1, tS, tB, Ws, Ss);
+      __syncthreads();
+    }
+  }
+}
+
 constexpr int DAG_LDS_V = 64 * TLD;  // staged tile (V / result / the diagonal block's S and X)
 
 __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   __shared__ __attribute__((aligned(16))) double Vs[DAG_LDS_V];
+  __shared__ __attribute__((aligned(16))) double Ws[DAG_LDS_V];
+  __shared__ __attribute__((aligned(16))) double Ss[64 * 65];
+  __shared__ int s_walk[2];
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Pn[512];
@@ -302,6 +497,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   const int ntri = nt * (nt + 1) / 2;
   const int total = nt * nt + ntri;
   const int tid = threadIdx.x;
+  if (a.walker && blockIdx.x == 0) return dag_walker(a, rL, rU, Vs, Ws, Ss, Pn, Xch, &s_ready, s_walk);
   for (;;) {
     if (tid == 0) {
       int t = atomicAdd(a.ctrl, 1);
@@ -337,6 +533,28 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       continue;
     }
     const int j = t / nt, r = t - j * nt;
+    if (r == 0 && a.walker) {
+      // ---- H(j): what block step j of the walker needs from the other tiles, one step ahead
+      tile_load_neg(acc, a.A + (int64_t)j * NB * (ld + 1), ld);
+      TileAcc accB;
+      tile_zero(accB);
+      if (j > 0) {
+        tile_load_neg(accB, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
+        if (!acc_rows_t<true>(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB,
+                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, a.ctrl,
+                              &s_ready))
+          return abandon(a.info);
+      }
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
+      if (j > 0) tile_foreach(accB, [&](int m, int n, double v) { Ws[n * TLD + m] = -v; });
+      __syncthreads();
+      store_tile_sc1(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), ld);
+      if (j > 0) store_tile_sc1(Ws, rL, (unsigned)j * NB + (unsigned)(j - 1) * NB * (unsigned)ld, ld);
+      publish(a.fH + j, nullptr);
+      __syncthreads();
+      continue;
+    }
     if (r == 0) {
       // ---- D(j): the tile left of the diagonal, L_{j,j-1}, then F(j,j), by ONE workgroup. The
       // chain of diagonal tiles runs through L_{j,j-1} (it is the last term of S_jj); computed
@@ -504,10 +722,12 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
 }
 
 size_t spd_inverse_dag_ctrl_bytes(int nt) {
-  return (((size_t)(4 + 2 * nt * nt) * sizeof(int)) + 255) & ~(size_t)255;
+  return (((size_t)(4 + 2 * nt * nt + nt) * sizeof(int)) + 255) & ~(size_t)255;
 }
 
 static int g_dag_workgroups = 256;
+static int g_dag_walker = 1;
+void set_dag_walker(int v) { g_dag_walker = v; }
 static long long* g_dag_stamps = nullptr;
 void set_dag_workgroups(int v) { g_dag_workgroups = v; }
 void set_dag_stamps(void* p) { g_dag_stamps = static_cast<long long*>(p); }
@@ -536,6 +756,8 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   a.ctrl = ctrl;
   a.fL = ctrl + 4;
   a.fU = ctrl + 4 + nt * nt;
+  a.fH = ctrl + 4 + 2 * nt * nt;
+  a.walker = g_dag_walker ? 1 : 0;
   a.logdet = logdet;
   a.info = info;
   a.stamps = g_dag_stamps;
@@ -547,7 +769,8 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
   MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   const int total = nt * nt + nt * (nt + 1) / 2;
-  const int grid = total < g_dag_workgroups ? total : g_dag_workgroups;
+  // (walker mode: workgroup 0 walks the diagonal chain, the others take the tickets)
+  const int grid = (total < g_dag_workgroups ? total : g_dag_workgroups) + a.walker;
   hipLaunchKernelGGL(spd_inverse_dag_kernel, dim3(grid), dim3(256), 0, st, a);
   return check_hip(hipGetLastError(), "spd_inverse_dag");
 }
