@@ -96,17 +96,17 @@ static int check_small(int M, int nmax) {
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
                      void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
-                     const double* cov_fac) {
+                     const double* cov_fac, bool have_inverse) {
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = ((N + 63) / 64) * 64;
   Work wk(work, Np);
   int rc;
   if (sh) cov_fac = nullptr;  // (Y Y^T needs every block row of Y: not with sharded rows)
-  {
-    Prof pf(PROF_COV_GRID, st);
-    if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
-  }
-  {
+  if (!have_inverse) {  // (else: theta0_prefactor_impl left K_0^-1, log|K_0| and info in `work`)
+    {
+      Prof pf(PROF_COV_GRID, st);
+      if ((rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st))) return rc;
+    }
     Prof pf(PROF_SPD_INVERSE, st);
     if ((rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st))) return rc;
   }
@@ -141,6 +141,19 @@ int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, do
   h_out3[2] = h4[2];
   if (h_info) *h_info = (int)h4[3];
   return 0;
+}
+
+int theta0_prefactor_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                          void* work, int dag_grid, hipStream_t st) {
+  if (N < 1) return fail(2, "N must be >= 1");
+  const int Np = ((N + 63) / 64) * 64;
+  Work wk(work, Np);
+  if (int rc = launch_se_cov_grid(N, Np, grid, theta1, theta2, pen_diag, wk.A0, st)) return rc;
+  Prof pf(PROF_SPD_INVERSE, st);
+  set_dag_grid_once(dag_grid);
+  const int rc = launch_spd_inverse(Np, wk.A0, wk.scal + 0, wk.iinfo + 0, wk.inv, st);
+  set_dag_grid_once(0);
+  return rc;
 }
 
 int estep_cov_factor(int N, void* work, double* V, hipStream_t st) {
@@ -197,7 +210,7 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
                       const double* mean, const double* m0, const double* cov, int m, double factr,
                       double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,
                       double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
-                      const Theta0Shard* sh, const double* cov_fac) {
+                      const Theta0Shard* sh, const double* cov_fac, bool first_have_inverse) {
   if (N < 1) return fail(2, "N must be >= 1");
   if (!h_theta0 || !h_theta_out) return fail(2, "theta0_mstep: NULL argument");
   magma_lbfgsb* opt = magma_lbfgsb_create(1, 2, h_theta0, m, factr, pgtol, maxit);
@@ -212,7 +225,7 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
     double out3[3] = {0.0, 0.0, 0.0};
     int info = 0;
     if ((rc = theta0_eval_impl(N, grid, x[0], x[1], pen_diag, mean, m0, cov, 1, work, out3, &info, st,
-                               sh, cov_fac)))
+                               sh, cov_fac, first && first_have_inverse)))
       break;
     const double f = (info == 0) ? out3[0] : __builtin_nan("");  // not SPD: as a failed evaluation
     if (first && h_f_x0) *h_f_x0 = f;
@@ -571,6 +584,10 @@ int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, co
 
 int magma_set_option(const char* name, long value) {
   if (!name) return fail(2, "option name is NULL");
+  if (std::string(name) == "prefactor") {  // first theta_0 inverse of an M-step started under the E-step
+    set_prefactor(value != 0);
+    return 0;
+  }
   if (std::string(name) == "cov_factor") {  // theta_0 gradient through the E-step's factor of cov
     set_covfac(value != 0);
     return 0;

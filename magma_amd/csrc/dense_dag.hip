@@ -726,6 +726,8 @@ size_t spd_inverse_dag_ctrl_bytes(int nt) {
 }
 
 static int g_dag_workgroups = 256;
+static thread_local int t_dag_grid_once = 0;  // workgroups of this thread's NEXT launch (0 = default)
+void set_dag_grid_once(int v) { t_dag_grid_once = v; }
 static int g_dag_walker = 1;
 void set_dag_walker(int v) { g_dag_walker = v; }
 static long long* g_dag_stamps = nullptr;
@@ -770,7 +772,9 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   const int total = nt * nt + nt * (nt + 1) / 2;
   // (walker mode: workgroup 0 walks the diagonal chain, the others take the tickets)
-  const int grid = (total < g_dag_workgroups ? total : g_dag_workgroups) + a.walker;
+  const int want = t_dag_grid_once > 0 ? t_dag_grid_once : g_dag_workgroups;
+  t_dag_grid_once = 0;
+  const int grid = (total < want ? total : want) + a.walker;
   hipLaunchKernelGGL(spd_inverse_dag_kernel, dim3(grid), dim3(256), 0, st, a);
   return check_hip(hipGetLastError(), "spd_inverse_dag");
 }

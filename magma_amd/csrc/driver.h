@@ -20,12 +20,20 @@ struct Theta0Shard {
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
                      void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
-                     const double* cov_fac = nullptr);
+                     const double* cov_fac = nullptr, bool have_inverse = false);
+// K_0(theta, pen_diag)^-1, log|K_0| and info into `work`, asynchronously on st, with dag_grid
+// workgroups for the tile-graph inverse (0 = default): the first evaluation of a theta_0 M-step
+// needs nothing from the E-step for this part, so the driver starts it next to the E-step's own
+// inverse (two latency-bound inverses side by side cost little more than one) and passes
+// have_inverse / first_have_inverse to the evaluation that follows on the same workspace.
+int theta0_prefactor_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                          void* work, int dag_grid, hipStream_t st);
 int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double pen_diag,
                       const double* mean, const double* m0, const double* cov, int m, double factr,
                       double pgtol, int maxit, void* work, double* h_theta_out, double* h_f_out,
                       double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, hipStream_t st,
-                      const Theta0Shard* sh, const double* cov_fac = nullptr);
+                      const Theta0Shard* sh, const double* cov_fac = nullptr,
+                      bool first_have_inverse = false);
 // cov_fac (optional, one rank only): V = L^-1 of the precision the E-step just inverted, lower
 // triangular, cov = V^T V (estep_cov_factor below). The gradient's K_0^-1 cov K_0^-1 is then
 // Y Y^T with Y = K_0^-1 V^T -- a triangular product (N^3) and the lower tiles of a symmetric one
@@ -58,6 +66,8 @@ bool prefetch_enabled();
 void set_prefetch(bool on);
 bool covfac_enabled();
 void set_covfac(bool on);
+bool prefactor_enabled();
+void set_prefactor(bool on);
 
 // out4 = (sum f, sum g[:,0], sum g[:,1], sum g[:,2]) over M entries, fixed order (g may be null)
 int launch_sum4(int64_t M, const double* f, const double* g, double* out4, hipStream_t st);

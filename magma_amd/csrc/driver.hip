@@ -73,11 +73,12 @@ int nccl_check(ncclResult_t e, const char* what) {
 // ------------------------------------------------------------------ context
 struct magma_ctx {
   int device = 0, rank = 0, world = 1;
-  hipStream_t main = nullptr, side = nullptr;
+  hipStream_t main = nullptr, side = nullptr, low = nullptr;
   ncclComm_t comm = nullptr;       // RCCL (world > 1), or
   magma_allreduce_fn cb = nullptr;  // a caller-supplied all-reduce
   void* cb_user = nullptr;
   int reserve_cus = 64;  // compute units kept free of the resident M-step while theta_0 runs
+  int prefactor_wgs = 96;  // workgroups of the theta_0 inverse that runs next to the E-step's
   int ncu = 256;
 
   // sum over ranks, in place, of n doubles in device memory; ordered on `st`
@@ -153,10 +154,19 @@ struct magma_dataset {
   DevBuf P2, w2, theta2, info2, f2;
   DevBuf covfac;  // V = L^-1 of the last E-step's precision (cov = V^T V); see driver.h
   bool covfac_ok = false;
+  // the theta_0 chain's own workspace, and the inverse of its first evaluation started early
+  // (theta0_prefactor_impl, driver.h)
+  DevBuf work0;
+  hipEvent_t pre0_ev = nullptr;
+  bool pre0_issued = false;
+  double pre0_key[3] = {0, 0, 0};
   hipEvent_t pre_ev = nullptr;
   bool pre_valid = false, pre_issued = false;
   std::vector<double> pre_theta;
-  ~magma_dataset() { if (pre_ev) (void)hipEventDestroy(pre_ev); }
+  ~magma_dataset() {
+    if (pre_ev) (void)hipEventDestroy(pre_ev);
+    if (pre0_ev) (void)hipEventDestroy(pre0_ev);
+  }
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
   double a0_key[3] = {0, 0, 0};
@@ -480,10 +490,12 @@ static int ctx_common(magma_ctx* c, int device) {
   // high priority: the theta_0 chain is a long sequence of small dependent kernels that should
   // not queue behind the wide per-individual launches it overlaps with
   MAGMA_CHECK_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+  MAGMA_CHECK_HIP(hipStreamCreateWithPriority(&c->low, hipStreamNonBlocking, lo));
   hipDeviceProp_t prop;
   MAGMA_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("MAGMA_RESERVE_CUS")) c->reserve_cus = atoi(e);
+  if (const char* e = getenv("MAGMA_PREFACTOR_WGS")) c->prefactor_wgs = atoi(e);
   return 0;
 }
 
@@ -546,6 +558,7 @@ void magma_ctx_destroy(magma_ctx* c) {
   if (c->comm && rccl().ok) (void)rccl().destroy(c->comm);
   if (c->main) (void)hipStreamDestroy(c->main);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->low) (void)hipStreamDestroy(c->low);
   delete c;
 }
 
@@ -653,7 +666,7 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
       (rc = d->sel.alloc(sizeof(int) * Mb)) || (rc = d->order.alloc(sizeof(int) * Mb)) || (rc = d->fsum.alloc(sizeof(double) * 16)) ||
       (rc = d->P.alloc(sizeof(double) * Np * Np)) || (rc = d->w.alloc(sizeof(double) * Np)) ||
       (rc = d->mean.alloc(sizeof(double) * Np)) || (rc = d->m0.alloc(sizeof(double) * Np)) ||
-      (rc = d->work.alloc(magma_workspace_bytes(N))) ||
+      (rc = d->work.alloc(magma_workspace_bytes(N))) || (rc = d->work0.alloc(magma_workspace_bytes(N))) ||
       (rc = d->cpack.alloc(sizeof(double) * Mb * (size_t)magma_cpack_stride(d->nmax))) ||
       (rc = d->rx.alloc(sizeof(double) * 3 * Mb)) || (rc = d->rf.alloc(sizeof(double) * Mb)) ||
       (rc = d->rfx0.alloc(sizeof(double) * Mb)) || (rc = d->rit.alloc(sizeof(int) * Mb)) ||
@@ -666,6 +679,7 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
         (rc = d->f2.alloc(sizeof(double) * Mb)))
       return rc;
     MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->pre_ev, hipEventDisableTiming));
+    MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->pre0_ev, hipEventDisableTiming));
   }
   if (c->has_comm()) {
     // all-reduce staging: lower 64 x 64 tiles of P, contiguous; the gathered theta_i
@@ -916,6 +930,13 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   std::string err0;
   double th0_new[2] = {h_theta0[0], h_theta0[1]};
   int nfev0 = 0;
+  // the first evaluation's K_0^-1 may already be in the workspace (magma_em_iteration)
+  const bool pre0 = d->pre0_issued && d->pre0_key[0] == h_theta0[0] && d->pre0_key[1] == h_theta0[1] &&
+                    d->pre0_key[2] == pen;
+  if (d->pre0_issued) {  // (taken or not: it writes the workspace the chain is about to use)
+    MAGMA_CHECK_HIP(hipStreamWaitEvent(c->side, d->pre0_ev, 0));
+    d->pre0_issued = false;
+  }
   auto run0 = [&]() {
     (void)hipSetDevice(c->device);
     Theta0Shard sh{c->rank, c->world, d->plist.as<int>(), d->nplist,
@@ -924,9 +945,9 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                    }, c};
     rc0 = theta0_mstep_impl(d->N, d->grid.as<double>(), h_theta0, pen, d->mean.as<double>(),
                             d->m0.as<double>(), d->P.as<double>(), o.m, o.factr, o.pgtol, o.maxit,
-                            d->work.p, th0_new, nullptr, nullptr, nullptr, &nfev0, nullptr, c->side,
+                            d->work0.p, th0_new, nullptr, nullptr, nullptr, &nfev0, nullptr, c->side,
                             c->has_comm() ? &sh : nullptr,
-                            d->covfac_ok ? d->covfac.as<double>() : nullptr);
+                            d->covfac_ok ? d->covfac.as<double>() : nullptr, pre0);
     if (rc0) err0 = magma_last_error();
   };
   // theta_0 and the theta_i problems overlap only when neither side needs the communicator at
@@ -948,7 +969,6 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if (!joined) {
       joined = true;
       set_resident_max_workgroups(0);
-      d->a0_valid = false;  // the workspace holds K_0^-1 of the last TRIAL point
       d->stats.theta0_evals += nfev0;
     }
     if (rc0) return fail(rc0, err0);
@@ -1096,6 +1116,21 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   const double nanv = std::numeric_limits<double>::quiet_NaN();
   const double pen_e = mean_sigma(d, h_theta_i, 3, 1.0);  // CF:381 (signed mean)
   int info = 0;
+  if (prefactor_enabled() && d->pre0_ev && d->Np / 64 <= 64 && !d->pre0_issued) {
+    // K_0^-1 of the M-step's first theta_0 evaluation (CF:409: pen_diag = mean(2 sigma_i)) depends
+    // on nothing the E-step computes: started now on the low-priority stream with a part of the
+    // chip, it is ready when the theta_0 chain begins
+    if (int rc = set_device(c)) return rc;
+    const double pen_m = mean_sigma(d, h_theta_i, 3, 2.0);
+    if (int rc = theta0_prefactor_impl(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_m,
+                                       d->work0.p, c->prefactor_wgs, c->low))
+      return rc;
+    MAGMA_CHECK_HIP(hipEventRecord(d->pre0_ev, c->low));
+    d->pre0_issued = true;
+    d->pre0_key[0] = h_theta0[0];
+    d->pre0_key[1] = h_theta0[1];
+    d->pre0_key[2] = pen_m;
+  }
   if (int rc = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr)) return rc;
   if (info != 0)
     return fail(5, std::string("E-step: ") + (info > 0 ? "K_0" : "hyper-posterior precision") +

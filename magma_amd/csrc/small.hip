@@ -1453,6 +1453,9 @@ void set_prefetch(bool on) { g_prefetch.store(on); }
 static std::atomic<bool> g_covfac{true};
 bool covfac_enabled() { return g_covfac.load(); }
 void set_covfac(bool on) { g_covfac.store(on); }
+static std::atomic<bool> g_prefactor{true};
+bool prefactor_enabled() { return g_prefactor.load(); }
+void set_prefactor(bool on) { g_prefactor.store(on); }
 
 int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx, const double* mean,
                          const double* cov, int64_t ldc, double* S, double* cpack, double* y_out,
