@@ -156,6 +156,15 @@ int theta0_prefactor_impl(int N, const double* grid, double theta1, double theta
   return rc;
 }
 
+// Diagnostic words of the last tile-graph inverse run on `work` (late steps of the walker; the
+// flag a workgroup gave up on | its block index << 16), for error messages after info = -999.
+int dag_diag(int N, void* work, int* h_two) {
+  const int Np = ((N + 63) / 64) * 64;
+  Work wk(work, Np);
+  const int* ctrl = reinterpret_cast<const int*>(wk.inv + 2 * (size_t)Np * Np);
+  return check_hip(hipMemcpy(h_two, ctrl + 2, 2 * sizeof(int), hipMemcpyDeviceToHost), "dag_diag");
+}
+
 int estep_cov_factor(int N, void* work, double* V, hipStream_t st) {
   const int Np = ((N + 63) / 64) * 64;
   Work wk(work, Np);

@@ -50,9 +50,9 @@ struct DagArgs {
   double* U;   // upper tiles incl. diagonal: U = L^-T
   int* fL;     // nt x nt flags, [i * nt + k]: tile (i, k) of L published (k == i: X_ii and U_ii)
   int* fU;     // nt x nt flags, [c * nt + k]: tile (c, k) of U published (k == c: same as fL)
-  int* ctrl;   // [0] ticket counter, [1] abort word
+  int* ctrl;   // [0] ticket counter, [1] abort word, [2], [3] diagnostics, [4] walker claim
   int* fH;     // nt flags (walker mode): S~_jj and B_j of block step j parked in L(j,j) / L(j,j-1)
-  int walker;  // 1: workgroup 0 walks the chain of diagonal tiles (see dag_walker)
+  int walker;  // 1: one workgroup (the first to start) walks the chain of diagonal tiles (dag_walker)
   double* logdet;
   int* info;
   long long* stamps;  // diagnostic (MAGMA_DAG_STAMPS builds): 8 wall-clock stamps per ticket
@@ -88,7 +88,11 @@ __device__ __forceinline__ int poll_ready(const int* fA, const int* fB, int k, i
         int ab = __hip_atomic_load(ctrl + 1, MAGMA_RLX_AGENT);
         if (spins >= SPIN_LIMIT) {
           ab = 1;
-          if (lane == 0) __hip_atomic_store(ctrl + 1, 1, MAGMA_RLX_AGENT);
+          if (lane == 0) {
+            // diagnostic: which flag this workgroup gave up on (index relative to ctrl), who
+            __hip_atomic_store(ctrl + 3, (int)((fA + k) - ctrl) | ((int)blockIdx.x << 16), MAGMA_RLX_AGENT);
+            __hip_atomic_store(ctrl + 1, 1, MAGMA_RLX_AGENT);
+          }
         }
         if (ab != 0) {
           r = -1;
@@ -322,7 +326,7 @@ __device__ __forceinline__ void walker_park(int q, int j, const v4u (&tS)[2048 /
   }
 }
 
-// The chain of diagonal tiles walked by ONE workgroup (workgroup 0, outside the ticket order).
+// The chain of diagonal tiles walked by ONE workgroup (outside the ticket order).
 // With a task per block step (D(j) below) every step pays: X_{j-1,j-1} stored, drained, flagged,
 // polled by the next step's workgroup and fetched back from L2 -- 3-4 of the 21 us a step takes.
 // Here X stays in LDS from one step to the next. What a step needs from the rest of the graph,
@@ -333,7 +337,8 @@ __device__ __forceinline__ void walker_park(int q, int j, const v4u (&tS)[2048 /
 // during which the two wavefronts that have no part in it fetch its tiles into LDS. Step j:
 //   L_{j,j-1} = B_j X_{j-1,j-1}^T (both in LDS) -> S = S~ - L L^T -> 64 x 64 factor -> X_jj, U_jj.
 // The walker holds no ticket and waits only for H tasks; a worker only ever waits for earlier
-// tickets or for the walker, so with one worker resident the graph drains.
+// tickets or for the walker, which is running by the time any worker starts (see the kernel), so
+// with one worker resident the graph drains.
 __device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t rU, double* Vs,
                                            double* Ws, double* Ss, double* Pn, double* Xch,
                                            int* s_ready, int* s_walk) {
@@ -497,7 +502,18 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   const int ntri = nt * (nt + 1) / 2;
   const int total = nt * nt + ntri;
   const int tid = threadIdx.x;
-  if (a.walker && blockIdx.x == 0) return dag_walker(a, rL, rU, Vs, Ws, Ss, Pn, Xch, &s_ready, s_walk);
+  if (a.walker) {
+    // the FIRST workgroup of this launch that starts running walks the chain (claimed with an
+    // atomic, not by block index: the order in which workgroups reach a compute unit is up to
+    // the dispatcher and to whatever else occupies the chip -- with several of these kernels in
+    // flight, workers of one could otherwise fill the compute units the other's walker needs,
+    // and the other way round). A worker therefore never runs before its walker does.
+    if (tid == 0) s_ticket = atomicCAS(a.ctrl + 4, 0, 1);
+    __syncthreads();
+    const int claimed = s_ticket;
+    __syncthreads();
+    if (claimed == 0) return dag_walker(a, rL, rU, Vs, Ws, Ss, Pn, Xch, &s_ready, s_walk);
+  }
   for (;;) {
     if (tid == 0) {
       int t = atomicAdd(a.ctrl, 1);
@@ -722,7 +738,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
 }
 
 size_t spd_inverse_dag_ctrl_bytes(int nt) {
-  return (((size_t)(4 + 2 * nt * nt + nt) * sizeof(int)) + 255) & ~(size_t)255;
+  return (((size_t)(8 + 2 * nt * nt + nt) * sizeof(int)) + 255) & ~(size_t)255;
 }
 
 static int g_dag_workgroups = 256;
@@ -756,9 +772,9 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   a.U = work + n2;
   int* ctrl = reinterpret_cast<int*>(work + 2 * n2);
   a.ctrl = ctrl;
-  a.fL = ctrl + 4;
-  a.fU = ctrl + 4 + nt * nt;
-  a.fH = ctrl + 4 + 2 * nt * nt;
+  a.fL = ctrl + 8;
+  a.fU = ctrl + 8 + nt * nt;
+  a.fH = ctrl + 8 + 2 * nt * nt;
   a.walker = g_dag_walker ? 1 : 0;
   a.logdet = logdet;
   a.info = info;
@@ -771,7 +787,7 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
   MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   const int total = nt * nt + nt * (nt + 1) / 2;
-  // (walker mode: workgroup 0 walks the diagonal chain, the others take the tickets)
+  // (walker mode: one more workgroup -- whichever starts first walks the diagonal chain)
   const int want = t_dag_grid_once > 0 ? t_dag_grid_once : g_dag_workgroups;
   t_dag_grid_once = 0;
   const int grid = (total < want ? total : want) + a.walker;

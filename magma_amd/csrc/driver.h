@@ -40,6 +40,7 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
 // (N^3) instead of a full product (2 N^3) and the lower tiles (N^3).
 // After magma_estep_finish on `work`: V <- U^T, U = L^-T as left in the workspace by the inverse.
 int estep_cov_factor(int N, void* work, double* V, hipStream_t st);
+int dag_diag(int N, void* work, int* h_two);
 
 // logL_GP_mod + gr_GP_mod (CF:181-201, 304-332) of ONE individual with more observations than a
 // wavefront handles (n > 64), on the dense kernels: the theta_0 evaluation chain on the

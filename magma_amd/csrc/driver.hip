@@ -1132,9 +1132,18 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
     d->pre0_key[2] = pen_m;
   }
   if (int rc = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr)) return rc;
-  if (info != 0)
+  if (info != 0) {
+    std::string extra;
+    if (info == 999 || info == -999) {  // the tile-graph inverse gave up on a flag: say which
+      int dg[2] = {0, 0};
+      (void)dag_diag(d->N, d->work.p, dg);
+      extra = "; tile graph abandoned: late steps " + std::to_string(dg[0]) + ", flag index " +
+              std::to_string(dg[1] & 0xffff) + ", workgroup " + std::to_string(dg[1] >> 16) +
+              ", nt " + std::to_string(d->Np / 64);
+    }
     return fail(5, std::string("E-step: ") + (info > 0 ? "K_0" : "hyper-posterior precision") +
-                       " not positive definite (info=" + std::to_string(info) + ")");
+                       " not positive definite (info=" + std::to_string(info) + ")" + extra);
+  }
   if (int rc = magma_m_step(c, d, h_theta0, h_theta_i, common_hp, opt4, h_theta0_out, h_theta_i_out))
     return rc;
   bool bad = std::isnan(h_theta0_out[0]) || std::isnan(h_theta0_out[1]);
