@@ -242,7 +242,7 @@ __device__ __forceinline__ void potrf_diag_block(double (&d)[16], double* Ls, do
 // Cholesky of the staged tile S (S[m * 65 + n], lower triangle valid) in wavefront 0, the
 // identity carried along in wavefront 1 (chol64_factor / chol64_solve): 200 MFMAs + 16 4x4
 // factorisations instead of 64 barrier-separated column steps and a 64-step triangular solve.
-// Called by ALL wavefronts of the workgroup. LDS: Pn[512] (Pn, Bn), Xch[1024].
+// Called by ALL wavefronts of the workgroup. LDS: Pn[512] (Pn, Bn), Xch[CHOL64_XCH].
 __device__ __forceinline__ void potrf_diag_block_mfma(const double* S, double* Pn, double* Xch,
                                                       int k, int64_t ld, double* __restrict__ X,
                                                       double* __restrict__ U,
@@ -261,16 +261,16 @@ __device__ __forceinline__ void potrf_diag_block_mfma(const double* S, double* P
           const int r = 16 * it + g + 4 * v, c = 16 * jt + l;
           A[it][jt][v] = (r >= c) ? S[r * 65 + c] : S[c * 65 + r];
         }
+    chol64_factor(A, Pn, Xch, lane);
+  } else if (wave == 1) {
+    v4d B[4][4];
     double pm = 1.0;
     int pe = 0, bad = 0;
-    chol64_factor(A, Pn, Xch, lane, pm, pe, bad);
+    chol64_solve(B, Pn + 256, Xch, lane, pm, pe, bad);
     if (lane == 0) {
       logdet[0] += log(pm) + (double)pe * 0.69314718055994530941723212145818;
       if (bad != 0 && info[0] == 0) info[0] = k * NB + bad;
     }
-  } else if (wave == 1) {
-    v4d B[4][4];
-    chol64_solve(B, Pn + 256, Xch, lane);
     double* Ukk = U + (int64_t)k * NB * (ld + 1);
     double* Xkk = X + (int64_t)k * NB * (ld + 1);
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void potrf_diag0_kernel(const double* __restri
 #else
   __shared__ double Ls[64 * 65];
   __shared__ __attribute__((aligned(16))) double Pn[512];
-  __shared__ __attribute__((aligned(16))) double Xch[1024];
+  __shared__ __attribute__((aligned(16))) double Xch[CHOL64_XCH];
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int m = e & 63, n = e >> 6;
     Ls[m * 65 + n] = A[m + (int64_t)n * ld];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
 #else
   __shared__ __attribute__((aligned(16))) double Ls[64 * 65];  // staged diagonal tile; its head
   __shared__ __attribute__((aligned(16))) double Pn[512];      // doubles as the operand slabs
-  __shared__ __attribute__((aligned(16))) double Xch[1024];
+  __shared__ __attribute__((aligned(16))) double Xch[CHOL64_XCH];
   static_assert(2 * 16 * TLD <= 64 * 65, "operand slabs must fit the staging tile");
   double* As = Ls;
   double* Bs = As + 16 * TLD;

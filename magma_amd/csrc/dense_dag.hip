@@ -239,6 +239,43 @@ __device__ __forceinline__ bool times_xt(const double* Vs, rsrc_t rx, unsigned o
   return true;
 }
 
+// acc(m, n) += sum_{k < 64} Am[k * TLD + m] Bm[k * TLD + n], both operands staged in LDS in
+// operand layout. The fragment reads run a batch of four k-groups ahead of the MFMAs: left alone
+// the compiler puts each k-group's reads right in front of its MFMAs and waits for them, 16
+// exposed LDS latencies per product on the chain of diagonal tiles.
+__device__ __forceinline__ void lds_product64(const double* Am, const double* Bm, TileAcc& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fo = (lane >> 4) * TLD + (lane & 15);
+  double fa[2][4][2], fb[2][4][2];  // two batches of 4 k-groups in flight
+  auto load = [&](int bt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 16 * bt + 4 * q;
+      fa[bt & 1][q][0] = Am[kk * TLD + fo + wm * 32];
+      fa[bt & 1][q][1] = Am[kk * TLD + fo + wm * 32 + 16];
+      fb[bt & 1][q][0] = Bm[kk * TLD + fo + wn * 32];
+      fb[bt & 1][q][1] = Bm[kk * TLD + fo + wn * 32 + 16];
+    }
+  };
+  load(0);
+#pragma unroll
+  for (int bt = 0; bt < 4; ++bt) {
+    if (bt + 1 < 4) load(bt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double a0 = fa[bt & 1][q][0], a1 = fa[bt & 1][q][1];
+      const double b0 = fb[bt & 1][q][0], b1 = fb[bt & 1][q][1];
+      acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc.c[0][0], 0, 0, 0);
+      acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc.c[0][1], 0, 0, 0);
+      acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc.c[1][0], 0, 0, 0);
+      acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc.c[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // acc <- -A(m, n) for the 64 x 64 tile at A (plain loads: the input is only read in this launch).
 __device__ __forceinline__ void tile_load_neg(TileAcc& acc, const double* __restrict__ A, int ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,33 +405,13 @@ __device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t r
       // B_j is in Ws[k * TLD + m], X_{j-1,j-1} in Vs[k * TLD + n] = X(n, k) since the last step
       TileAcc out;
       tile_zero(out);
-#pragma unroll
-      for (int kk = 0; kk < 64; kk += 4) {
-        const double fa0 = Ws[kk * TLD + fo + wm * 32];
-        const double fa1 = Ws[kk * TLD + fo + wm * 32 + 16];
-        const double fb0 = Vs[kk * TLD + fo + wn * 32];
-        const double fb1 = Vs[kk * TLD + fo + wn * 32 + 16];
-        out.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, out.c[0][0], 0, 0, 0);
-        out.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, out.c[0][1], 0, 0, 0);
-        out.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, out.c[1][0], 0, 0, 0);
-        out.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, out.c[1][1], 0, 0, 0);
-      }
+      lds_product64(Ws, Vs, out);
       __syncthreads();  // every wavefront has read Ws and Vs
       DAG_STAMP(ts, 1);
       tile_foreach(out, [&](int m, int n, double v) { Ws[n * TLD + m] = v; });  // L_{j,j-1}
       __syncthreads();
       store_tile_sc1(Ws, rL, offB, ld);
-#pragma unroll
-      for (int kk = 0; kk < 64; kk += 4) {  // acc = L L^T
-        const double fa0 = Ws[kk * TLD + fo + wm * 32];
-        const double fa1 = Ws[kk * TLD + fo + wm * 32 + 16];
-        const double fb0 = Ws[kk * TLD + fo + wn * 32];
-        const double fb1 = Ws[kk * TLD + fo + wn * 32 + 16];
-        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
-        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
-        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
-        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
-      }
+      lds_product64(Ws, Ws, acc);  // acc = L L^T
     }
     // S = S~ - L L^T staged for the factor as Vs[m * 65 + n] (X of the last step is dead: every
     // wavefront passed the barrier after the product)
@@ -415,17 +432,17 @@ __device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t r
             const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
             S[it][jt][v] = (rr >= cc) ? Vs[rr * 65 + cc] : Vs[cc * 65 + rr];
           }
+      chol64_factor(S, Pn, Xch, lane);
+      __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
+    } else if (wave == 1) {
+      v4d B[4][4];
       double pm = 1.0;
       int pe = 0, bad = 0;
-      chol64_factor(S, Pn, Xch, lane, pm, pe, bad);
+      chol64_solve(B, Pn + 256, Xch, lane, pm, pe, bad);
       if (lane == 0) {
         atomicAdd(a.logdet, log(pm) + (double)pe * 0.69314718055994530941723212145818);
         if (bad != 0) atomicCAS(a.info, 0, j * NB + bad);
       }
-      __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
-    } else if (wave == 1) {
-      v4d B[4][4];
-      chol64_solve(B, Pn + 256, Xch, lane);
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < 4; ++it)
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Pn[512];
-  __shared__ __attribute__((aligned(16))) double Xch[1024];
+  __shared__ __attribute__((aligned(16))) double Xch[CHOL64_XCH];
   __shared__ int s_ticket;
   __shared__ int s_ready;
   static_assert(64 * 65 <= DAG_LDS_V, "diagonal block staging must fit");
@@ -600,22 +617,8 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
         tile_foreach(out, [&](int m, int n, double v) { Vs[n * TLD + m] = v; });
         __syncthreads();
         store_tile_sc1(Vs, rL, (unsigned)j * NB + (unsigned)(j - 1) * NB * (unsigned)ld, ld);
-        {  // acc += L_{j,j-1} L_{j,j-1}^T straight from LDS (Vs[k * TLD + m] = L(m, k))
-          const int lane_ = tid & 63, wave_ = tid >> 6;
-          const int wm = wave_ & 1, wn = wave_ >> 1;
-          const int fo = (lane_ >> 4) * TLD + (lane_ & 15);
-#pragma unroll
-          for (int kk = 0; kk < 64; kk += 4) {
-            const double fa0 = Vs[kk * TLD + fo + wm * 32];
-            const double fa1 = Vs[kk * TLD + fo + wm * 32 + 16];
-            const double fb0 = Vs[kk * TLD + fo + wn * 32];
-            const double fb1 = Vs[kk * TLD + fo + wn * 32 + 16];
-            acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
-            acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
-            acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
-            acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
-          }
-        }
+        // acc += L_{j,j-1} L_{j,j-1}^T straight from LDS (Vs[k * TLD + m] = L(m, k))
+        lds_product64(Vs, Vs, acc);
       }
       DAG_STAMP(t, 1);
       __syncthreads();  // (also ends the reads of Vs above)
@@ -639,18 +642,18 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
               const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
               S[it][jt][v] = (rr >= cc) ? Vs[rr * 65 + cc] : Vs[cc * 65 + rr];
             }
+        chol64_factor(S, Pn, Xch, lane);
+        __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
+      } else if (wave == 1) {
+        v4d B[4][4];
         double pm = 1.0;
         int pe = 0, bad = 0;
-        chol64_factor(S, Pn, Xch, lane, pm, pe, bad);
+        chol64_solve(B, Pn + 256, Xch, lane, pm, pe, bad);
         if (lane == 0) {
           // steps are ordered by the flag chain, so the adds arrive in step order
           atomicAdd(a.logdet, log(pm) + (double)pe * 0.69314718055994530941723212145818);
           if (bad != 0) atomicCAS(a.info, 0, j * NB + bad);
         }
-        __syncthreads();  // S was read before the factor's barriers; X may now overwrite it
-      } else if (wave == 1) {
-        v4d B[4][4];
-        chol64_solve(B, Pn + 256, Xch, lane);
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4; ++it)

@@ -79,6 +79,10 @@ struct magma_ctx {
   void* cb_user = nullptr;
   int reserve_cus = 64;  // compute units kept free of the resident M-step while theta_0 runs
   int prefactor_wgs = 96;  // workgroups of the theta_0 inverse that runs next to the E-step's
+  // workgroups of the monitoring call's inverse while the next E-step's sums run next to it (a
+  // tile-graph workgroup fills its compute unit: with the full grid nothing else is dispatched
+  // until it is over and the two run one after the other); 0 = full grid
+  int monitor_wgs = 160;
   int ncu = 256;
 
   // sum over ranks, in place, of n doubles in device memory; ordered on `st`
@@ -142,7 +146,9 @@ struct magma_dataset {
   int64_t nP = 0, nw = 0;
   DevBuf theta, f, g, info, sel, fsum;
   DevBuf P, w, mean, m0, work, cpack, pack;
-  DevBuf rx, rf, rfx0, rit, rnf, rst, gath;
+  // resident M-step results: x (3 M), f (M), f(x0) (M) doubles, evaluation counts (M ints)
+  DevBuf rres, rit, rst, gath;
+  void* h_rres = nullptr;  // pinned mirror
   DevBuf plist;  // lower tiles of the theta_0 gradient owned by this rank
   int nplist = 0;
   bool cpack_ok = false, have_order = false;
@@ -166,6 +172,7 @@ struct magma_dataset {
   ~magma_dataset() {
     if (pre_ev) (void)hipEventDestroy(pre_ev);
     if (pre0_ev) (void)hipEventDestroy(pre0_ev);
+    if (h_rres) (void)hipHostFree(h_rres);
   }
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
@@ -496,6 +503,7 @@ static int ctx_common(magma_ctx* c, int device) {
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("MAGMA_RESERVE_CUS")) c->reserve_cus = atoi(e);
   if (const char* e = getenv("MAGMA_PREFACTOR_WGS")) c->prefactor_wgs = atoi(e);
+  if (const char* e = getenv("MAGMA_MONITOR_WGS")) c->monitor_wgs = atoi(e);
   return 0;
 }
 
@@ -668,9 +676,8 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
       (rc = d->mean.alloc(sizeof(double) * Np)) || (rc = d->m0.alloc(sizeof(double) * Np)) ||
       (rc = d->work.alloc(magma_workspace_bytes(N))) || (rc = d->work0.alloc(magma_workspace_bytes(N))) ||
       (rc = d->cpack.alloc(sizeof(double) * Mb * (size_t)magma_cpack_stride(d->nmax))) ||
-      (rc = d->rx.alloc(sizeof(double) * 3 * Mb)) || (rc = d->rf.alloc(sizeof(double) * Mb)) ||
-      (rc = d->rfx0.alloc(sizeof(double) * Mb)) || (rc = d->rit.alloc(sizeof(int) * Mb)) ||
-      (rc = d->rnf.alloc(sizeof(int) * Mb)) || (rc = d->rst.alloc(sizeof(int) * Mb)))
+      (rc = d->rres.alloc(sizeof(double) * 6 * Mb)) || (rc = d->rit.alloc(sizeof(int) * Mb)) ||
+      (rc = d->rst.alloc(sizeof(int) * Mb)))
     return rc;
   if (M > 0) {
     if ((rc = d->P2.alloc(sizeof(double) * Np * Np)) || (rc = d->w2.alloc(sizeof(double) * Np)) ||
@@ -1019,15 +1026,26 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
         if ((rc = magma_indiv_mstep_resident(0, (int)M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
                                              d->y.as<double>(), d->idx.as<int>(), d->mean.as<double>(),
                                              d->cpack.as<double>(), d->theta.as<double>(), order, o.m,
-                                             o.factr, o.pgtol, o.maxit, d->rx.as<double>(),
-                                             d->rf.as<double>(), d->rfx0.as<double>(), d->rit.as<int>(),
-                                             d->rnf.as<int>(), d->rst.as<int>(), st)))
+                                             o.factr, o.pgtol, o.maxit, d->rres.as<double>(),
+                                             d->rres.as<double>() + 3 * M, d->rres.as<double>() + 4 * M,
+                                             d->rit.as<int>(),
+                                             reinterpret_cast<int*>(d->rres.as<double>() + 5 * M),
+                                             d->rst.as<int>(), st)))
           break;
-        if ((rc = d2h(hx.data(), d->rx.p, sizeof(double) * 3 * (size_t)M, st)) ||
-            (rc = d2h(hf.data(), d->rf.p, sizeof(double) * (size_t)M, st)) ||
-            (rc = d2h(hfx0.data(), d->rfx0.p, sizeof(double) * (size_t)M, st)) ||
-            (rc = d2h(hnf.data(), d->rnf.p, sizeof(int) * (size_t)M, st)) || (rc = sync(st)))
+        // x, f, f(x0) and the evaluation counts sit in one block: one copy into pinned memory
+        if (!d->h_rres &&
+            (rc = check_hip(hipHostMalloc(&d->h_rres, sizeof(double) * 6 * (size_t)M, hipHostMallocDefault),
+                            "hipHostMalloc")))
           break;
+        if ((rc = d2h(d->h_rres, d->rres.p, sizeof(double) * 6 * (size_t)M, st)) || (rc = sync(st))) break;
+        {
+          const double* hr = static_cast<const double*>(d->h_rres);
+          std::copy(hr, hr + 3 * M, hx.begin());
+          std::copy(hr + 3 * M, hr + 4 * M, hf.begin());
+          std::copy(hr + 4 * M, hr + 5 * M, hfx0.begin());
+          const int* hn = reinterpret_cast<const int*>(hr + 5 * M);
+          std::copy(hn, hn + M, hnf.begin());
+        }
         HT("m: resident (launch + d2h sync)");
         {  // next call's order: by evaluation count, descending, stable (counting sort)
           int top = 0;
@@ -1162,7 +1180,10 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   HT("em: prefetch launch");
   const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
   double ll0 = 0.0;
-  if (int rc = theta0_f(c, d, h_theta0_out, sig, &ll0)) return rc;
+  if (d->pre_issued && c->monitor_wgs > 0) set_dag_grid_once(c->monitor_wgs);
+  const int rc_mon = theta0_f(c, d, h_theta0_out, sig, &ll0);
+  set_dag_grid_once(0);
+  if (rc_mon) return rc_mon;
   h_logl2[1] = -ll0 - d->last_sum_fi_new;
   HT("em: monitoring (sync)");
   return 0;

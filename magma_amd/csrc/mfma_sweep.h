@@ -262,25 +262,33 @@ __device__ __forceinline__ void chol4_inverse(const double (&p)[4][4], double (&
   M[3][0] = s3 * m30; M[3][1] = s3 * m31; M[3][2] = s3 * m32; M[3][3] = s3;
 }
 
-// Two wavefronts of one workgroup: right-looking Cholesky of the 64 x 64 SPD matrix A
-// (accumulator layout, both triangles) in blocks of 4 columns, applied at the same time to
-// B = I, which ends as X = L^-1 (lower triangular, exact zeros above the diagonal).
-// Block J (rows/columns 4b..4b+3):
-//   FACTOR wavefront (owns A):
-//     M = L_JJ^-1 (chol4_inverse of A[J,J], every lane redundantly);
-//     panel  Lp[i][g] = sum_h A[i][4b+h] M[g][h]  (rows i >= 4b; A's rows J are already in
-//            A-fragment layout by symmetry, the 4 x 4 product needs the other lane groups'
-//            values: through LDS);
-//     A -= Lp Lp^T on the tiles at or below/right of J (one MFMA per tile, Lp is both fragments);
-//     Lp and this lane's row of M published to the SOLVE wavefront (slot b & 1 of Xch), barrier.
-//   SOLVE wavefront (owns B), one block behind:
-//     X[J,:] = M B[J,:] (same kind of LDS exchange), B -= Lp X[J,:] on the rows below, X[J,:]
-//            stored over B[J,:].
+// Two wavefronts of one workgroup: right-looking factorisation of the 64 x 64 SPD matrix A
+// (accumulator layout; the tiles on and above the diagonal are used) in blocks of 4 columns,
+// applied at the same time to B = I, which ends as X = L^-1 (L = the Cholesky factor; lower
+// triangular, exact zeros above the diagonal).
+// The FACTOR wavefront's per-block chain (pivot block -> its factor -> panel -> the MFMAs that
+// produce the next pivot block) is what a block step of the N x N factorisation waits for, so it
+// carries only what the chain needs: the factorisation runs in LDL' form (no square roots), and
+// everything that can wait -- the 1/sqrt(d) row scaling of X, log-det, the SPD test -- is done by
+// the SOLVE wavefront from the pivots FACTOR publishes.
+// Block J (rows/columns 4b..4b+3), P = A[J,J] = Lu D Lu' (Lu unit lower), Mu = Lu^-1:
+//   FACTOR (owns A):
+//     Q = A[:,J] Mu' (rows i >= 4b; A's rows J are already in A-fragment layout by symmetry, the
+//         4 x 4 product needs the other lane groups' values: through LDS), Qs = Q D^-1;
+//     A -= Qs Q' (= Lp Lp' with the Cholesky panel Lp = Q D^-1/2) on the tiles at or right of J:
+//         the tile row that holds the next block's rows first, the rest spread over the next
+//         block's serial part;
+//     Qs, this lane's row of Mu and the pivots published to SOLVE (slot b & 1 of Xch), barrier.
+//   SOLVE (owns B), one block behind:
+//     Y[J,:] = Mu B[J,:] (same kind of LDS exchange), B -= Qs Y[J,:] on the rows below,
+//     X[J,:] = D^-1/2 Y[J,:] stored over B[J,:]; det *= prod(D), SPD test on D.
 // 120 + 80 MFMAs in all; the two chains overlap, so the workgroup's time is the FACTOR chain's.
 // Every wavefront of the workgroup must execute the 16 barriers (chol64_idle for the others).
-// Pn, Bn: 256 doubles of LDS each (private to FACTOR / SOLVE); Xch: 2 x 512 doubles.
-__device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane,
-                                              double& pm, int& pe, int& info) {
+// Pn, Bn: 256 doubles of LDS each (private to FACTOR / SOLVE); Xch: CHOL64_XCH doubles.
+constexpr int CHOL64_SLOT = 8 * 64 + 8;     // Qs (4 x 64), Mu rows (4 x 64), 4 pivots
+constexpr int CHOL64_XCH = 2 * CHOL64_SLOT;
+
+__device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane) {
   const int l = lane & 15, g = lane >> 4;
   double gm[4];
 #pragma unroll
@@ -288,68 +296,122 @@ __device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double
     gm[h] = (g == h) ? 1.0 : 0.0;
     asm volatile("" : "+v"(gm[h]));
   }
+  double q[4] = {0.0, 0.0, 0.0, 0.0}, nqs[4] = {0.0, 0.0, 0.0, 0.0};  // block b - 1's Q, -Qs
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
     const int it0 = b >> 2, v0 = b & 3;
+    // the previous block's update of the tiles outside this block's tile row: issued a few at a
+    // time between the stages below (the matrix core works on them under the pivot chain)
+    constexpr int NPEND_MAX = 6;
+    int pit[NPEND_MAX], pjt[NPEND_MAX], npend = 0;
+    if (b > 0) {
+      const int pi0 = (b - 1) >> 2;
+#pragma unroll
+      for (int it = pi0; it < 4; ++it)
+#pragma unroll
+        for (int jt = it; jt < 4; ++jt)
+          if (it != it0 && (it > pi0 || ((b - 1) & 3) != 3)) {  // (a finished tile row needs no update)
+            pit[npend] = it;
+            pjt[npend] = jt;
+            ++npend;
+          }
+    }
+    auto pending = [&](int k, int nk) {  // share k of nk
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < NPEND_MAX; ++e)
+        if (e < npend && e >= k * npend / nk && e < (k + 1) * npend / nk)
+          A[pit[e]][pjt[e]] =
+              __builtin_amdgcn_mfma_f64_16x16x4f64(nqs[pit[e]], q[pjt[e]], A[pit[e]][pjt[e]], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
     for (int jt = it0; jt < 4; ++jt) Pn[(16 * jt + l) * 4 + g] = A[it0][jt][v0];
     __builtin_amdgcn_wave_barrier();
-    double P4[4][4], M[4][4], piv[4];
+    pending(0, 5);
+    double p[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double2 lo = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4 + 2]);
-      P4[r][0] = lo.x; P4[r][1] = lo.y; P4[r][2] = hi.x; P4[r][3] = hi.y;
+      p[r][0] = lo.x; p[r][1] = lo.y; p[r][2] = hi.x; p[r][3] = hi.y;
     }
-    int bad;
-    chol4_inverse(P4, M, piv, bad);
-    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int e;
-      pm *= frexp(piv[k], &e);
-      pe += e;
-    }
-    if ((b & 7) == 7) {
-      int e;
-      pm = frexp(pm, &e);
-      pe += e;
-    }
-    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
-    // row g of M for this lane (0/1 weights: exact, and no divergent select chains)
+    // LDL' of the pivot block (lower triangle read); Mu = Lu^-1
+    const double d0 = p[0][0];
+    const double r0 = fast_rcp(d0);
+    const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
+    const double d1 = fma(-l10, p[1][0], p[1][1]);
+    const double p21 = fma(-l20, p[1][0], p[2][1]);
+    const double p31 = fma(-l30, p[1][0], p[3][1]);
+    double p22 = fma(-l20, p[2][0], p[2][2]);
+    double p32 = fma(-l30, p[2][0], p[3][2]);
+    double p33 = fma(-l30, p[3][0], p[3][3]);
+    pending(1, 5);
+    const double r1 = fast_rcp(d1);
+    const double l21 = p21 * r1, l31 = p31 * r1;
+    p22 = fma(-l21, p21, p22);
+    p32 = fma(-l31, p21, p32);
+    p33 = fma(-l31, p31, p33);
+    const double d2 = p22;
+    pending(2, 5);
+    const double r2 = fast_rcp(d2);
+    const double l32 = p32 * r2;
+    const double d3 = fma(-l32, p32, p33);
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -fma(l21, m10, l20);
+    const double m31 = -fma(l32, m21, l31);
+    pending(3, 5);
+    const double r3 = fast_rcp(d3);
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+    // row g of Mu and 1/d_g for this lane (0/1 weights: exact, and no divergent select chains)
     double mr[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h)
-      mr[h] = fma(gm[3], M[3][h], fma(gm[2], M[2][h], fma(gm[1], M[1][h], gm[0] * M[0][h])));
-    double lp[4];
+    mr[0] = fma(gm[3], m30, fma(gm[2], m20, fma(gm[1], m10, gm[0])));
+    mr[1] = fma(gm[3], m31, fma(gm[2], m21, gm[1]));
+    mr[2] = fma(gm[3], m32, gm[2]);
+    mr[3] = gm[3];
+    const double rg = fma(gm[3], r3, fma(gm[2], r2, fma(gm[1], r1, gm[0] * r0)));
+    const double dg = fma(gm[3], d3, fma(gm[2], d2, fma(gm[1], d1, gm[0] * d0)));
+    pending(4, 5);
+    double* slot = Xch + CHOL64_SLOT * (b & 1);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       if (it < it0) {
-        lp[it] = 0.0;
+        q[it] = 0.0;
+        nqs[it] = 0.0;
         continue;
       }
       const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4 + 2]);
       const double v = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
-      lp[it] = (it > it0 || l >= 4 * v0) ? v : 0.0;  // rows above the block are finished
+      q[it] = (it > it0 || l >= 4 * v0) ? v : 0.0;  // rows above the block are finished
+      nqs[it] = -(q[it] * rg);
+      slot[it * 64 + lane] = nqs[it];
     }
-    double* slot = Xch + 512 * (b & 1);
-#pragma unroll
-    for (int it = it0; it < 4; ++it) slot[it * 64 + lane] = lp[it];
 #pragma unroll
     for (int h = 0; h < 4; ++h) slot[(4 + h) * 64 + lane] = mr[h];
+    if (l == 0) slot[512 + g] = dg;
     __syncthreads();  // barrier b: block b published; the slot of block b-2 may be reused
+    // the tile row of the next block's rows first; the others with the next block (`pending`)
+    const int it1 = (b + 1) >> 2;
+    if (b + 1 < 16) {
 #pragma unroll
-    for (int it = it0; it < 4; ++it)
-#pragma unroll
-      for (int jt = it0; jt < 4; ++jt)
-        A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], lp[jt], A[it][jt], 0, 0, 0);
+      for (int jt = it1; jt < 4; ++jt)
+        A[it1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nqs[it1], q[jt], A[it1][jt], 0, 0, 0);
+    }
   }
 }
 
+// pm, pe accumulate det = pm * 2^pe over the pivots; info = index + 1 of the first pivot that is
+// not a positive finite number (kept if already set).
 __device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const double* Xch,
-                                             int lane) {
+                                             int lane, double& pm, int& pe, int& info) {
   const int l = lane & 15, g = lane >> 4;
+  double gm[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    gm[h] = (g == h) ? 1.0 : 0.0;
+    asm volatile("" : "+v"(gm[h]));
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -362,26 +424,48 @@ __device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const d
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) Bn[(16 * jt + l) * 4 + g] = B[it0][jt][v0];
     __syncthreads();  // barrier b
-    const double* slot = Xch + 512 * (b & 1);
-    double mr[4], lp[4], xr[4];
+    const double* slot = Xch + CHOL64_SLOT * (b & 1);
+    double mr[4], nqs[4], yr[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) mr[h] = slot[(4 + h) * 64 + lane];
 #pragma unroll
-    for (int it = it0; it < 4; ++it) lp[it] = slot[it * 64 + lane];
+    for (int it = it0; it < 4; ++it) nqs[it] = slot[it * 64 + lane];
+    const double2 dlo = *reinterpret_cast<const double2*>(&slot[512]);
+    const double2 dhi = *reinterpret_cast<const double2*>(&slot[514]);
+    const double d[4] = {dlo.x, dlo.y, dhi.x, dhi.y};
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) {
       const double2 lo = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4]);
       const double2 hi = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4 + 2]);
-      xr[jt] = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
+      yr[jt] = fma(hi.y, mr[3], fma(hi.x, mr[2], fma(lo.y, mr[1], lo.x * mr[0])));
     }
     __builtin_amdgcn_wave_barrier();  // Bn is rewritten by the next block
 #pragma unroll
     for (int it = it0; it < 4; ++it)
 #pragma unroll
       for (int jt = 0; jt <= it0; ++jt)
-        B[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[it], xr[jt], B[it][jt], 0, 0, 0);
+        B[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nqs[it], yr[jt], B[it][jt], 0, 0, 0);
+    // off the FACTOR chain: SPD test, determinant, the 1/sqrt(d) scaling of the finished rows
+    int bad = 0;
 #pragma unroll
-    for (int jt = 0; jt <= it0; ++jt) B[it0][jt][v0] = xr[jt];
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = (d[k] > 0.0) && (d[k] < 1.7e308);
+      bad = (!ok && bad == 0) ? k + 1 : bad;
+      int e;
+      pm *= frexp(d[k], &e);
+      pe += e;
+    }
+    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
+    if ((b & 7) == 7) {
+      int e;
+      pm = frexp(pm, &e);
+      pe += e;
+    }
+    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
+    const double dg = fma(gm[3], d[3], fma(gm[2], d[2], fma(gm[1], d[1], gm[0] * d[0])));
+    const double sg = fast_rsqrt(dg);
+#pragma unroll
+    for (int jt = 0; jt <= it0; ++jt) B[it0][jt][v0] = yr[jt] * sg;
   }
 }
 

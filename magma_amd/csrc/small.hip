@@ -498,12 +498,24 @@ __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
     __syncthreads();
     if ((int)threadIdx.x < n) ibuf[threadIdx.x] = idx[o + threadIdx.x];
     __syncthreads();
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    // all of a thread's reads are in flight before the first is used: written as a plain loop
+    // (read, two LDS stores, next read) the compiler waits for every read in turn, and the
+    // kernel's time is (n^2 / 256) serial memory latencies per individual
+    constexpr int SLOTS = MAGMA_NSMALL_MAX * MAGMA_NSMALL_MAX / 256;
+    double gv[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int e = (int)threadIdx.x + 256 * q;
       const int r = e % n, c = e / n;
-      if (r >= c) {
-        const double v = cov[(int64_t)ibuf[c] * ldc + ibuf[r]];
-        Cl[r * LDC + c] = v;
-        Cl[c * LDC + r] = v;
+      gv[q] = (e < n * n && r >= c) ? cov[(int64_t)ibuf[c] * ldc + ibuf[r]] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int e = (int)threadIdx.x + 256 * q;
+      const int r = e % n, c = e / n;
+      if (e < n * n && r >= c) {
+        Cl[r * LDC + c] = gv[q];
+        Cl[c * LDC + r] = gv[q];
       }
     }
     __syncthreads();
