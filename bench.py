@@ -275,8 +275,16 @@ def main():
         torch.cuda.synchronize()
         return reps / (time.perf_counter() - t1)
     pen_e = float(np.mean(theta_i[:, 2]))
-    rates = {"e_step_per_s": rate(lambda: eng.e_step(theta0, theta_i, pen_e, 0.0)),
-             "logL_monitoring_per_s": rate(lambda: eng.logL_monitoring(theta0, theta_i))}
+    rates = {"e_step_per_s": rate(lambda: eng.e_step(theta0, theta_i, pen_e, 0.0))}
+    # M-step alone (on the hyper-posterior the E-step above left resident), and its rate in sweeps:
+    # one sweep = one f + grad f evaluation of every individual (theta_0 evaluations run next to them)
+    eng.reset_stats()
+    rates["m_step_per_s"] = rate(lambda: eng.m_step(theta0, theta_i, common))
+    st_m = eng.stats
+    sweeps = (st_m["common_evals"] if common else st_m["indiv_evals"] / max(1, eng.hi - eng.lo)) / 4.0
+    rates["m_step_sweeps_per_s"] = rates["m_step_per_s"] * sweeps
+    rates["m_step_counts"] = {"sweeps_per_m_step": sweeps, "theta0_evals_per_m_step": st_m["theta0_evals"] / 4.0}
+    rates["logL_monitoring_per_s"] = rate(lambda: eng.logL_monitoring(theta0, theta_i))
 
     if rank == 0:
         N, n, Mloc = cfg["N"], cfg["n"], eng.hi - eng.lo

@@ -208,6 +208,7 @@ struct HostTiming {
   }
 };
 HostTiming g_ht;
+double g_ht_prev_join = 0.0;
 #define HT(label) g_ht.mark(label)
 
 struct Opt {
@@ -1101,6 +1102,10 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     // the theta_0 thread may still be using the communicator: wait for it before this thread does
     if (int r2 = join0()) rc = rc ? rc : r2;
     HT("m: join theta_0");
+    if (g_ht.on && getenv("MAGMA_HOST_TIMING")[0] == '2')
+      fprintf(stderr, "[magma m-step] theta_0 evaluations %d, wait for the theta_0 chain after the resident kernel %.2f ms\n",
+              nfev0, g_ht.acc["m: join theta_0"].second * 1e-3 - g_ht_prev_join);
+    if (g_ht.on) g_ht_prev_join = g_ht.acc["m: join theta_0"].second * 1e-3;
     if (!rc && c->has_comm()) {
       double* gb = d->gath.as<double>();
       rc = check_hip(hipMemsetAsync(gb, 0, sizeof(double) * 3 * (size_t)Mt, st), "m_step gather");
