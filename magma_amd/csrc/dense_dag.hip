@@ -52,7 +52,8 @@ struct DagArgs {
   int* fU;     // nt x nt flags, [c * nt + k]: tile (c, k) of U published (k == c: same as fL)
   int* ctrl;   // [0] ticket counter, [1] abort word, [2], [3] diagnostics, [4] walker claim
   int* fH;     // nt flags (walker mode): S~_jj and B_j of block step j parked in L(j,j) / L(j,j-1)
-  int walker;  // 1: one workgroup (the first to start) walks the chain of diagonal tiles (dag_walker)
+  int* fS;     // nt flags (walker 2): S~_jj parked by its own task HS(j); fH[j] then announces B_j only
+  int walker;  // 1, 2: one workgroup (the first to start) walks the chain of diagonal tiles (dag_walker / dag_walker2)
   double* logdet;
   int* info;
   long long* stamps;  // diagnostic (MAGMA_DAG_STAMPS builds): 8 wall-clock stamps per ticket
@@ -326,8 +327,13 @@ __device__ __forceinline__ void abandon(int* info) {
   do {                                                                           \
     if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(t) * 8 + (s)] = (long long)wall_clock64(); \
   } while (0)
+#define DAG_STAMP_T(t, s, who)                                                   \
+  do {                                                                           \
+    if (a.stamps != nullptr && threadIdx.x == (who)) a.stamps[(t) * 8 + (s)] = (long long)wall_clock64(); \
+  } while (0)
 #else
 #define DAG_STAMP(t, s) do { } while (0)
+#define DAG_STAMP_T(t, s, who) do { } while (0)
 #endif
 
 // The two tiles block step j of the walker needs (see dag_walker), requested by NTHR threads
@@ -499,6 +505,261 @@ __device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t r
   }
 }
 
+// ------------------------------------------------------------------ walker, second generation
+// The same chain, with the two products of a block step taken off it. In dag_walker a step is
+//   L_{j,j-1} = B_j X_{j-1}^T  ->  S_jj = S~_jj - L L^T  ->  64 x 64 factor  ->  X_jj,
+// all four wavefronts in lock step (the factor's per-block workgroup barriers), two of them idle
+// during the factor. But X_jj leaves the SOLVE wavefront four rows at a time, and column c of
+// L_{j+1,j} = B_{j+1} X_jj^T needs rows <= c of X_jj only. Here the factor's two wavefronts talk
+// through LDS counters instead of barriers (Chol64Flags), SOLVE exports X_jj (to LDS, and U_jj to
+// memory) block by block, and the other two wavefronts ("updaters") work one step ahead while the
+// factor of step j runs: fetch B_{j+1} and S~_{j+1} when H(j+1) has parked them, then per batch
+// of 16 columns -- as soon as those rows of X_jj exist -- the columns of L_{j+1,j} (triangular:
+// 4 (k + 1) k-blocks in batch k), their store, and S_{j+1,j+1} -= L_batch L_batch^T (lower tiles,
+// in registers). When the factor ends only the last batch is left. One workgroup barrier per
+// step; every wait is an LDS (or flag) poll with a bound that raises the abort word.
+// LDS: Vs = X_jj (operand layout), Ws = B_{j+1}, Ss = S_jj staged for the factor, Lb[2] = the
+// batches of L (the workers' As / Bs), sy = counters (monotonic over the steps: no reset).
+constexpr int WS_PUB = 0, WS_CONS = 1, WS_XROW = 2, WS_ABORT = 3, WS_PARK = 4, WS_LB = 5, WS_XST = 9,
+              WS_LST = 10, WS_WORDS = 16;
+
+// this wavefront has arrived; wait until `target` arrivals are in
+__device__ __forceinline__ bool lds_arrive_wait(int* ctr, int target, int* abort_) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return lds_wait_ge(ctr, target, abort_);
+}
+
+// a flag another workgroup raises (all lanes of one wavefront poll it)
+__device__ __forceinline__ bool wave_wait_flag(const int* flag, int* ctrl, int* abort_) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(flag, MAGMA_RLX_AGENT) != 0) return true;
+    __builtin_amdgcn_s_sleep(8);
+    if ((spins & 255u) == 255u) {
+      if (spins >= SPIN_LIMIT || __hip_atomic_load(ctrl + 1, MAGMA_RLX_AGENT) != 0)
+        __hip_atomic_store(abort_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+    }
+  }
+}
+
+__device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t rU, double* Vs,
+                                            double* Ws, double* Ss, double* Lb0, double* Lb1,
+                                            double* Pn, double* Xch, int* sy, int* s_ready) {
+  const int nt = a.nt, ld = a.ld;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & 15, g = lane >> 4;
+  int* abort_ = sy + WS_ABORT;
+  if (tid < WS_WORDS) sy[tid] = 0;
+  {  // step 0's tile (S_00 = A_00, parked by H(0)), by everybody
+    if (poll_ready(a.fH, a.fH, 0, 1, a.ctrl, s_ready) < 0) return abandon(a.info);
+    v4u tS[8], tB[8];
+    walker_fetch<256>(tid, 0, rL, ld, tS, tB);
+    walker_park<256>(tid, 0, tS, tB, Ws, Ss);
+    __syncthreads();
+  }
+  for (int j = 0; j < nt; ++j) {
+    const unsigned offD = (unsigned)j * NB * (unsigned)(ld + 1);
+    const bool next = j + 1 < nt;
+    const unsigned offD1 = (unsigned)(j + 1) * NB * (unsigned)(ld + 1);  // S~_{j+1}: tile (j+1, j+1)
+    const unsigned offB1 = (unsigned)(j + 1) * NB + (unsigned)j * NB * (unsigned)ld;  // (j+1, j)
+    const int ts = nt * nt + nt * (nt + 1) / 2 + j;
+    (void)ts;
+    DAG_STAMP(ts, 0);
+    Chol64Flags fs{sy + WS_PUB, sy + WS_CONS, abort_, 16 * j};
+    if (wave == 0) {
+      // ---- FACTOR, then its half of the X_jj tile store
+      v4d S[4][4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * it + g + 4 * v, cc = 16 * jt + l;
+            S[it][jt][v] = (rr >= cc) ? Ss[rr * 65 + cc] : Ss[cc * 65 + rr];
+          }
+      bool ok = chol64_factor(S, Pn, Xch, lane, fs);
+      ok = ok && lds_wait_ge(sy + WS_XROW, 16 * (j + 1), abort_);  // X_jj complete in Vs
+      DAG_STAMP(ts, 3);
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int u = lane + i * 128;
+          const int m2 = (u & 31) * 2, n = u >> 5;
+          const v4u v = *reinterpret_cast<const v4u*>(&Vs[n * TLD + m2]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rL, (offD + m2 + (unsigned)n * (unsigned)ld) * 8u, 0, AUX_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lds_arrive_wait(sy + WS_XST, 2 * (j + 1), abort_) && lane == 0) {
+          __hip_atomic_store(a.fL + j * nt + j, 1, MAGMA_RLX_AGENT);
+          __hip_atomic_store(a.fU + j * nt + j, 1, MAGMA_RLX_AGENT);
+        }
+      }
+    } else if (wave == 1) {
+      // ---- SOLVE: X_jj into Vs and U_jj = X_jj^T into memory as the rows are finished
+      v4d B[4][4];
+      double pm = 1.0;
+      int pe = 0, bad = 0;
+      const bool ok = chol64_solve(
+          B, Pn + 256, Xch, lane, pm, pe, bad, fs, [&](int b, int jt, double x) {
+            const int rr = 4 * b + g, cc = 16 * jt + l;  // X(rr, cc)
+            Vs[cc * TLD + rr] = x;
+            v2u xv;
+            __builtin_memcpy(&xv, &x, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(
+                xv, rU, (offD + (unsigned)cc + (unsigned)rr * (unsigned)ld) * 8u, 0, AUX_SC1);
+            if (jt == 3) lds_publish(sy + WS_XROW, 16 * j + b + 1);
+          });
+      if (ok) {
+        if (lane == 0) {
+          atomicAdd(a.logdet, log(pm) + (double)pe * 0.69314718055994530941723212145818);
+          if (bad != 0) atomicCAS(a.info, 0, j * NB + bad);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int u = 64 + lane + i * 128;
+          const int m2 = (u & 31) * 2, n = u >> 5;
+          const v4u v = *reinterpret_cast<const v4u*>(&Vs[n * TLD + m2]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rL, (offD + m2 + (unsigned)n * (unsigned)ld) * 8u, 0, AUX_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)lds_arrive_wait(sy + WS_XST, 2 * (j + 1), abort_);
+      }
+    } else if (next) {
+      // ---- updaters: step j + 1's S, from the rows of X_jj as they appear
+      const int u = wave - 2;       // 0 / 1
+      const int q128 = tid - 128;   // index among the updaters' threads
+      // lower tiles (mt, nt) of S owned by this wavefront: u = 0: row tiles 0, 3; u = 1: 1, 2
+      const int smt[5] = {u ? 1 : 0, u ? 1 : 3, u ? 2 : 3, u ? 2 : 3, u ? 2 : 3};
+      const int snt[5] = {0, u ? 1 : 0, u ? 0 : 1, u ? 1 : 2, u ? 2 : 3};
+      const int lmt[2] = {u ? 1 : 0, u ? 2 : 3};  // row tiles of L computed by this wavefront
+      // S~_{j+1} (HS(j+1): ready early) -> accumulators; then B_{j+1} (HB(j+1)) -> Ws
+      bool ok = wave_wait_flag(a.fS + j + 1, a.ctrl, abort_);
+      v4d Sa[5];
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned m = 16 * smt[i] + l, n = 16 * snt[i] + g + 4 * r;
+            const v2u w = __builtin_amdgcn_raw_buffer_load_b64(rL, (offD1 + m + n * (unsigned)ld) * 8u, 0, AUX_SC1);
+            double d;
+            __builtin_memcpy(&d, &w, 8);
+            Sa[i][r] = d;
+          }
+        ok = wave_wait_flag(a.fH + j + 1, a.ctrl, abort_);
+      }
+      DAG_STAMP_T(ts, 1, 128);
+      if (ok) {
+        v4u tB[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = q128 + i * 128;
+          const unsigned off = (unsigned)((e & 31) * 2) + (unsigned)(e >> 5) * (unsigned)ld;
+          tB[i] = __builtin_amdgcn_raw_buffer_load_b128(rL, (offB1 + off) * 8u, 0, AUX_SC1);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = q128 + i * 128;
+          *reinterpret_cast<v4u*>(&Ws[(e >> 5) * TLD + (e & 31) * 2]) = tB[i];
+        }
+        ok = lds_arrive_wait(sy + WS_PARK, 2 * (j + 1), abort_);
+        DAG_STAMP_T(ts, 2, 128);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok) break;
+        ok = lds_wait_ge(sy + WS_XROW, 16 * j + 4 * (k + 1), abort_);  // rows < 16 (k + 1) of X_jj
+        if (!ok) break;
+        double* Lb = (k & 1) ? Lb1 : Lb0;
+        v4d Lo[2];
+        Lo[0] = (v4d){0.0, 0.0, 0.0, 0.0};
+        Lo[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        {  // fragment reads run four k-blocks ahead of the MFMAs (see lds_product64)
+          double fb[2][4], fa0[2][4], fa1[2][4];
+          auto load = [&](int bt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int kk = 16 * bt + 4 * q + g;
+              fb[bt & 1][q] = Vs[kk * TLD + 16 * k + l];
+              fa0[bt & 1][q] = Ws[kk * TLD + 16 * lmt[0] + l];
+              fa1[bt & 1][q] = Ws[kk * TLD + 16 * lmt[1] + l];
+            }
+          };
+          load(0);
+#pragma unroll
+          for (int bt = 0; bt <= k; ++bt) {
+            if (bt + 1 <= k) load(bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              Lo[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[bt & 1][q], fa0[bt & 1][q], Lo[0], 0, 0, 0);
+              Lo[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[bt & 1][q], fa1[bt & 1][q], Lo[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Lb[(g + 4 * r) * TLD + 16 * lmt[t] + l] = Lo[t][r];
+        ok = lds_arrive_wait(sy + WS_LB + k, 2 * (j + 1), abort_);
+        if (!ok) break;
+        // the batch's 16 columns of L_{j+1,j} to memory
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = q128 + i * 128;
+          const int m2 = (e & 31) * 2, kk = e >> 5;
+          const v4u v = *reinterpret_cast<const v4u*>(&Lb[kk * TLD + m2]);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              v, rL, (offB1 + m2 + (unsigned)(16 * k + kk) * (unsigned)ld) * 8u, 0, AUX_SC1);
+        }
+        // S -= L_batch L_batch^T on this wavefront's lower tiles (all fragments read up front)
+        {
+          double fm[4][5], fn[4][5];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              fm[q][i] = -Lb[(4 * q + g) * TLD + 16 * smt[i] + l];
+              fn[q][i] = Lb[(4 * q + g) * TLD + 16 * snt[i] + l];
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+              Sa[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[q][i], fm[q][i], Sa[i], 0, 0, 0);
+        }
+        if (k == 2) DAG_STAMP_T(ts, 4, 128);
+        if (k == 3) {
+          // the tile L_{j+1,j} is complete: its flag goes up now (the stores drain under the MFMAs
+          // above), H(j + 2) and the F tasks of column j wait for it
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lds_arrive_wait(sy + WS_LST, 2 * (j + 1), abort_) && tid == 128)
+            __hip_atomic_store(a.fL + (j + 1) * nt + j, 1, MAGMA_RLX_AGENT);
+        }
+      }
+      if (ok) {
+        // S_{j+1,j+1} staged for the next factor (its lower triangle is what is read); the FACTOR
+        // wavefront read Ss long ago (at the start of its factor)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ss[(16 * smt[i] + l) * 65 + 16 * snt[i] + g + 4 * r] = Sa[i][r];
+        DAG_STAMP_T(ts, 5, 128);
+      }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+      if (tid == 0) __hip_atomic_store(a.ctrl + 1, 1, MAGMA_RLX_AGENT);
+      return abandon(a.info);
+    }
+  }
+}
+
 constexpr int DAG_LDS_V = 64 * TLD;  // staged tile (V / result / the diagonal block's S and X)
 
 __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
@@ -506,6 +767,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   __shared__ __attribute__((aligned(16))) double Ws[DAG_LDS_V];
   __shared__ __attribute__((aligned(16))) double Ss[64 * 65];
   __shared__ int s_walk[2];
+  __shared__ int s_sync[WS_WORDS];
   __shared__ __attribute__((aligned(16))) double As[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Bs[16 * TLD];
   __shared__ __attribute__((aligned(16))) double Pn[512];
@@ -529,7 +791,10 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
     __syncthreads();
     const int claimed = s_ticket;
     __syncthreads();
-    if (claimed == 0) return dag_walker(a, rL, rU, Vs, Ws, Ss, Pn, Xch, &s_ready, s_walk);
+    if (claimed == 0) {
+      if (a.walker == 2) return dag_walker2(a, rL, rU, Vs, Ws, Ss, As, Bs, Pn, Xch, s_sync, &s_ready);
+      return dag_walker(a, rL, rU, Vs, Ws, Ss, Pn, Xch, &s_ready, s_walk);
+    }
   }
   for (;;) {
     if (tid == 0) {
@@ -566,6 +831,38 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       continue;
     }
     const int j = t / nt, r = t - j * nt;
+    if (r == 0 && a.walker == 2 && j > 0) {
+      // ---- HB(j) (walker 2): B_j = A_{j,j-1} - sum_{k<j-1} L_jk L_{j-1,k}^T alone. Its last term
+      // needs the walker's own L_{j-1,j-2}, so it sits on the walker's critical cycle: S~_jj, which
+      // does not, has a task of its own (HS below) and half the MFMAs are gone from this one.
+      tile_load_neg(acc, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
+      if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB, a.fL + (j - 1) * nt,
+                    0, j - 1, ld, acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Ws[n * TLD + m] = -v; });
+      __syncthreads();
+      store_tile_sc1(Ws, rL, (unsigned)j * NB + (unsigned)(j - 1) * NB * (unsigned)ld, ld);
+      publish(a.fH + j, nullptr);
+      __syncthreads();
+      continue;
+    }
+    if (r == 1 && a.walker == 2 && j + 1 < nt) {
+      // ---- HS(j+1) (walker 2, in the slot of F(j+1,j), which the walker computes):
+      // S~_{j+1,j+1} = A_{j+1,j+1} - sum_{k<j} L_{j+1,k} L_{j+1,k}^T, parked in tile (j+1, j+1)
+      const int i = j + 1;
+      tile_load_neg(acc, a.A + (int64_t)i * NB * (ld + 1), ld);
+      if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)i * NB, a.fL + i * nt, 0, j, ld,
+                    acc, As, Bs, a.ctrl, &s_ready))
+        return abandon(a.info);
+      __syncthreads();
+      tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
+      __syncthreads();
+      store_tile_sc1(Vs, rL, (unsigned)i * NB * (unsigned)(ld + 1), ld);
+      publish(a.fS + i, nullptr);
+      __syncthreads();
+      continue;
+    }
     if (r == 0 && a.walker) {
       // ---- H(j): what block step j of the walker needs from the other tiles, one step ahead
       tile_load_neg(acc, a.A + (int64_t)j * NB * (ld + 1), ld);
@@ -741,13 +1038,13 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
 }
 
 size_t spd_inverse_dag_ctrl_bytes(int nt) {
-  return (((size_t)(8 + 2 * nt * nt + nt) * sizeof(int)) + 255) & ~(size_t)255;
+  return (((size_t)(8 + 2 * nt * nt + 2 * nt) * sizeof(int)) + 255) & ~(size_t)255;
 }
 
 static int g_dag_workgroups = 256;
 static thread_local int t_dag_grid_once = 0;  // workgroups of this thread's NEXT launch (0 = default)
 void set_dag_grid_once(int v) { t_dag_grid_once = v; }
-static int g_dag_walker = 1;
+static int g_dag_walker = 2;
 void set_dag_walker(int v) { g_dag_walker = v; }
 static long long* g_dag_stamps = nullptr;
 void set_dag_workgroups(int v) { g_dag_workgroups = v; }
@@ -778,7 +1075,8 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   a.fL = ctrl + 8;
   a.fU = ctrl + 8 + nt * nt;
   a.fH = ctrl + 8 + 2 * nt * nt;
-  a.walker = g_dag_walker ? 1 : 0;
+  a.fS = a.fH + nt;
+  a.walker = g_dag_walker < 0 ? 0 : (g_dag_walker > 2 ? 2 : g_dag_walker);
   a.logdet = logdet;
   a.info = info;
   a.stamps = g_dag_stamps;
@@ -793,7 +1091,7 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   // (walker mode: one more workgroup -- whichever starts first walks the diagonal chain)
   const int want = t_dag_grid_once > 0 ? t_dag_grid_once : g_dag_workgroups;
   t_dag_grid_once = 0;
-  const int grid = (total < want ? total : want) + a.walker;
+  const int grid = (total < want ? total : want) + (a.walker ? 1 : 0);
   hipLaunchKernelGGL(spd_inverse_dag_kernel, dim3(grid), dim3(256), 0, st, a);
   return check_hip(hipGetLastError(), "spd_inverse_dag");
 }

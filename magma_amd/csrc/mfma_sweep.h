@@ -288,7 +288,59 @@ __device__ __forceinline__ void chol4_inverse(const double (&p)[4][4], double (&
 constexpr int CHOL64_SLOT = 8 * 64 + 8;     // Qs (4 x 64), Mu rows (4 x 64), 4 pivots
 constexpr int CHOL64_XCH = 2 * CHOL64_SLOT;
 
-__device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane) {
+// How FACTOR hands a block to SOLVE.
+// Chol64Barrier: one workgroup barrier per block (every wavefront of the workgroup takes part:
+// chol64_idle for those with nothing to do).
+struct Chol64Barrier {
+  __device__ __forceinline__ bool before_write(int) { return true; }
+  __device__ __forceinline__ void published(int) { __syncthreads(); }
+  __device__ __forceinline__ bool wait_published(int) {
+    __syncthreads();
+    return true;
+  }
+  __device__ __forceinline__ void consumed(int) {}
+};
+
+// Wait until the LDS word *flag is >= want (all lanes of the calling wavefront). false: *abort was
+// raised by somebody, or this wait gave up (and raised it).
+__device__ __forceinline__ bool lds_wait_ge(const int* flag, int want, int* abort_) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+    if ((spins & 255u) == 255u) {
+      if (spins >= (1u << 22)) __hip_atomic_store(abort_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  return true;
+}
+
+__device__ __forceinline__ void lds_publish(int* flag, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Chol64Flags: two counters in LDS (blocks published by FACTOR, blocks taken by SOLVE) and no
+// barrier, so that the other wavefronts of the workgroup are free to do something else meanwhile.
+// The counters run on from one factorisation to the next (base = 16 x the number done so far), so
+// nobody has to reset them; between two factorisations the caller passes a workgroup barrier.
+struct Chol64Flags {
+  int* pub;
+  int* cons;
+  int* abort_;
+  int base;
+  __device__ __forceinline__ bool before_write(int b) {  // slot b & 1 held block b - 2
+    return b < 2 || lds_wait_ge(cons, base + b - 1, abort_);
+  }
+  __device__ __forceinline__ void published(int b) { lds_publish(pub, base + b + 1); }
+  __device__ __forceinline__ bool wait_published(int b) { return lds_wait_ge(pub, base + b + 1, abort_); }
+  __device__ __forceinline__ void consumed(int b) { lds_publish(cons, base + b + 1); }
+};
+
+template <class Sync>
+__device__ __forceinline__ bool chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane,
+                                              Sync sy) {
   const int l = lane & 15, g = lane >> 4;
   double gm[4];
 #pragma unroll
@@ -373,6 +425,7 @@ __device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double
     const double dg = fma(gm[3], d3, fma(gm[2], d2, fma(gm[1], d1, gm[0] * d0)));
     pending(4, 5);
     double* slot = Xch + CHOL64_SLOT * (b & 1);
+    if (!sy.before_write(b)) return false;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       if (it < it0) {
@@ -390,7 +443,7 @@ __device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double
 #pragma unroll
     for (int h = 0; h < 4; ++h) slot[(4 + h) * 64 + lane] = mr[h];
     if (l == 0) slot[512 + g] = dg;
-    __syncthreads();  // barrier b: block b published; the slot of block b-2 may be reused
+    sy.published(b);  // (barrier b: block b published; the slot of block b-2 may be reused)
     // the tile row of the next block's rows first; the others with the next block (`pending`)
     const int it1 = (b + 1) >> 2;
     if (b + 1 < 16) {
@@ -399,12 +452,22 @@ __device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double
         A[it1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nqs[it1], q[jt], A[it1][jt], 0, 0, 0);
     }
   }
+  return true;
+}
+
+__device__ __forceinline__ void chol64_factor(v4d (&A)[4][4], double* Pn, double* Xch, int lane) {
+  (void)chol64_factor(A, Pn, Xch, lane, Chol64Barrier());
 }
 
 // pm, pe accumulate det = pm * 2^pe over the pivots; info = index + 1 of the first pivot that is
 // not a positive finite number (kept if already set).
-__device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const double* Xch,
-                                             int lane, double& pm, int& pe, int& info) {
+// row_out(b, jt, x): the finished rows 4b .. 4b+3 of X as block b leaves them (this lane: row
+// 4b + g, column 16 jt + l; every jt, zeros above the diagonal), for callers that want X before
+// the last block is done.
+template <class Sync, class RowOut>
+__device__ __forceinline__ bool chol64_solve(v4d (&B)[4][4], double* Bn, const double* Xch,
+                                             int lane, double& pm, int& pe, int& info, Sync sy,
+                                             RowOut&& row_out) {
   const int l = lane & 15, g = lane >> 4;
   double gm[4];
 #pragma unroll
@@ -423,7 +486,7 @@ __device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const d
     const int it0 = b >> 2, v0 = b & 3;
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) Bn[(16 * jt + l) * 4 + g] = B[it0][jt][v0];
-    __syncthreads();  // barrier b
+    if (!sy.wait_published(b)) return false;  // (barrier b)
     const double* slot = Xch + CHOL64_SLOT * (b & 1);
     double mr[4], nqs[4], yr[4];
 #pragma unroll
@@ -433,6 +496,7 @@ __device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const d
     const double2 dlo = *reinterpret_cast<const double2*>(&slot[512]);
     const double2 dhi = *reinterpret_cast<const double2*>(&slot[514]);
     const double d[4] = {dlo.x, dlo.y, dhi.x, dhi.y};
+    sy.consumed(b);
 #pragma unroll
     for (int jt = 0; jt <= it0; ++jt) {
       const double2 lo = *reinterpret_cast<const double2*>(&Bn[(16 * jt + l) * 4]);
@@ -465,8 +529,17 @@ __device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const d
     const double dg = fma(gm[3], d[3], fma(gm[2], d[2], fma(gm[1], d[1], gm[0] * d[0])));
     const double sg = fast_rsqrt(dg);
 #pragma unroll
-    for (int jt = 0; jt <= it0; ++jt) B[it0][jt][v0] = yr[jt] * sg;
+    for (int jt = 0; jt < 4; ++jt) {
+      if (jt <= it0) B[it0][jt][v0] = yr[jt] * sg;
+      row_out(b, jt, jt <= it0 ? (double)B[it0][jt][v0] : 0.0);
+    }
   }
+  return true;
+}
+
+__device__ __forceinline__ void chol64_solve(v4d (&B)[4][4], double* Bn, const double* Xch,
+                                             int lane, double& pm, int& pe, int& info) {
+  (void)chol64_solve(B, Bn, Xch, lane, pm, pe, info, Chol64Barrier(), [](int, int, double) {});
 }
 
 __device__ __forceinline__ void chol64_idle() {
