@@ -518,8 +518,12 @@ __device__ __forceinline__ void dag_walker(const DagArgs& a, rsrc_t rL, rsrc_t r
 // 4 (k + 1) k-blocks in batch k), their store, and S_{j+1,j+1} -= L_batch L_batch^T (lower tiles,
 // in registers). When the factor ends only the last batch is left. One workgroup barrier per
 // step; every wait is an LDS (or flag) poll with a bound that raises the abort word.
-// LDS: Vs = X_jj (operand layout), Ws = B_{j+1}, Ss = S_jj staged for the factor, Lb[2] = the
+// LDS: Vs = X_jj (row-major, rows of XLD = 65 doubles: the SOLVE wavefront's lanes hold 16
+// consecutive columns of a row, and a column-major store at the operand stride of 80 doubles is an
+// 8-way bank conflict that made SOLVE the slower of the two), Ws = B_{j+1} (operand layout), Ss =
+// S_jj staged for the factor, Lb[2] = the
 // batches of L (the workers' As / Bs), sy = counters (monotonic over the steps: no reset).
+constexpr int XLD = 65;
 constexpr int WS_PUB = 0, WS_CONS = 1, WS_XROW = 2, WS_ABORT = 3, WS_PARK = 4, WS_LB = 5, WS_XST = 9,
               WS_LST = 10, WS_WORDS = 16;
 
@@ -588,7 +592,11 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
         for (int i = 0; i < 16; ++i) {
           const int u = lane + i * 128;
           const int m2 = (u & 31) * 2, n = u >> 5;
-          const v4u v = *reinterpret_cast<const v4u*>(&Vs[n * TLD + m2]);
+          double2 xp;
+          xp.x = Vs[m2 * XLD + n];
+          xp.y = Vs[(m2 + 1) * XLD + n];
+          v4u v;
+          __builtin_memcpy(&v, &xp, 16);
           __builtin_amdgcn_raw_buffer_store_b128(v, rL, (offD + m2 + (unsigned)n * (unsigned)ld) * 8u, 0, AUX_SC1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -605,7 +613,7 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
       const bool ok = chol64_solve(
           B, Pn + 256, Xch, lane, pm, pe, bad, fs, [&](int b, int jt, double x) {
             const int rr = 4 * b + g, cc = 16 * jt + l;  // X(rr, cc)
-            Vs[cc * TLD + rr] = x;
+            Vs[rr * XLD + cc] = x;
             v2u xv;
             __builtin_memcpy(&xv, &x, 8);
             __builtin_amdgcn_raw_buffer_store_b64(
@@ -621,7 +629,11 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
         for (int i = 0; i < 16; ++i) {
           const int u = 64 + lane + i * 128;
           const int m2 = (u & 31) * 2, n = u >> 5;
-          const v4u v = *reinterpret_cast<const v4u*>(&Vs[n * TLD + m2]);
+          double2 xp;
+          xp.x = Vs[m2 * XLD + n];
+          xp.y = Vs[(m2 + 1) * XLD + n];
+          v4u v;
+          __builtin_memcpy(&v, &xp, 16);
           __builtin_amdgcn_raw_buffer_store_b128(v, rL, (offD + m2 + (unsigned)n * (unsigned)ld) * 8u, 0, AUX_SC1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -683,7 +695,7 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int kk = 16 * bt + 4 * q + g;
-              fb[bt & 1][q] = Vs[kk * TLD + 16 * k + l];
+              fb[bt & 1][q] = Vs[(16 * k + l) * XLD + kk];
               fa0[bt & 1][q] = Ws[kk * TLD + 16 * lmt[0] + l];
               fa1[bt & 1][q] = Ws[kk * TLD + 16 * lmt[1] + l];
             }

@@ -481,6 +481,7 @@ __device__ __forceinline__ bool chol64_solve(v4d (&B)[4][4], double* Bn, const d
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int v = 0; v < 4; ++v) B[it][jt][v] = (it == jt && g + 4 * v == l) ? 1.0 : 0.0;
+  double dsave = 1.0;
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
     const int it0 = b >> 2, v0 = b & 3;
@@ -509,30 +510,41 @@ __device__ __forceinline__ bool chol64_solve(v4d (&B)[4][4], double* Bn, const d
 #pragma unroll
       for (int jt = 0; jt <= it0; ++jt)
         B[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nqs[it], yr[jt], B[it][jt], 0, 0, 0);
-    // off the FACTOR chain: SPD test, determinant, the 1/sqrt(d) scaling of the finished rows
-    int bad = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool ok = (d[k] > 0.0) && (d[k] < 1.7e308);
-      bad = (!ok && bad == 0) ? k + 1 : bad;
-      int e;
-      pm *= frexp(d[k], &e);
-      pe += e;
-    }
-    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
-    if ((b & 7) == 7) {
-      int e;
-      pm = frexp(pm, &e);
-      pe += e;
-    }
-    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
+    // off the FACTOR chain: the 1/sqrt(d) scaling of the finished rows; the pivots are kept for
+    // the SPD test and the determinant, done once at the end with one pivot per lane (block by
+    // block they cost this wavefront ~40 serial operations per block, and FACTOR waits for a
+    // SOLVE that falls two blocks behind)
     const double dg = fma(gm[3], d[3], fma(gm[2], d[2], fma(gm[1], d[1], gm[0] * d[0])));
+    dsave = (l == b) ? dg : dsave;  // lane (l = b, g) keeps pivot 4 b + g
     const double sg = fast_rsqrt(dg);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       if (jt <= it0) B[it0][jt][v0] = yr[jt] * sg;
       row_out(b, jt, jt <= it0 ? (double)B[it0][jt][v0] : 0.0);
     }
+  }
+  {
+    // lane (l, g) holds pivot p = 4 l + g: first bad pivot by ballot, det = product of mantissas
+    // x 2^(sum of exponents) over the wavefront in a fixed order
+    const bool ok = (dsave > 0.0) && (dsave < 1.7e308);
+    const int p = 4 * l + g;
+    int first = ok ? 64 : p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(first, o);
+      first = other < first ? other : first;
+    }
+    info = (first < 64 && info == 0) ? first + 1 : info;
+    int e;
+    double m = frexp(dsave, &e);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m *= __shfl_xor(m, o);
+      e += __shfl_xor(e, o);
+    }
+    int e2;
+    pm *= frexp(m, &e2);
+    pe += e + e2;
   }
   return true;
 }
