@@ -71,11 +71,17 @@ def test_gemm_nt_matches_numpy(gpu):
 # dag_workgroups: 256 = the one-launch tile-graph inverse (default), 3 = the same with fewer
 # workgroups than tasks in flight (its ticket order must not need co-residency), 0 = the
 # launch-per-step path it replaced.
-@pytest.fixture(params=[256, 3, 0], ids=["dag256", "dag3", "launches"])
+# dag_walker: who walks the chain of diagonal tiles: 2 = one workgroup whose wavefronts work a step
+# ahead of the factor (default), 1 = one workgroup in lock step, 0 = a task per block step.
+@pytest.fixture(params=[(256, 2), (3, 2), (256, 1), (3, 1), (256, 0), (0, 2)],
+                ids=["dag256", "dag3", "dag256-walker1", "dag3-walker1", "dag256-tasks", "launches"])
 def inverse_path(request, gpu):
-    gpu["_lib"].call("magma_set_option", b"dag_workgroups", C.c_long(request.param))
-    yield request.param
+    wgs, walker = request.param
+    gpu["_lib"].call("magma_set_option", b"dag_workgroups", C.c_long(wgs))
+    gpu["_lib"].call("magma_set_option", b"dag_walker", C.c_long(walker))
+    yield wgs
     gpu["_lib"].call("magma_set_option", b"dag_workgroups", C.c_long(256))
+    gpu["_lib"].call("magma_set_option", b"dag_walker", C.c_long(2))
 
 
 @pytest.mark.parametrize("N", [1, 37, 64, 65, 200, 450, 1100])
