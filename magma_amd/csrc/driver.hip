@@ -152,6 +152,7 @@ struct magma_dataset {
   DevBuf plist;  // lower tiles of the theta_0 gradient owned by this rank
   int nplist = 0;
   bool cpack_ok = false, have_order = false;
+  bool cpack_early = false;  // set by magma_em_iteration around its E-step
   // identical timestamps for all of this rank's individuals (CF:221-224, 347-350): with common
   // hyper-parameters their summed objective is M x one pseudo-individual's (small.hip, dedup_*)
   bool common_times = false, dedup_ok = false;
@@ -884,6 +885,10 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   d->a0_key[1] = h_theta0[1];
   d->a0_key[2] = pen_diag;
   d->last_f0 = f0;
+  // inside an EM iteration with individual hyper-parameters the M-step's first need is the packed
+  // cov blocks: the gather is queued here, ahead of the small kernels and host round trips below
+  if (info == 0 && d->cpack_early)
+    if ((rc = ensure_cpack(d, st))) return rc;
   d->covfac_ok = false;
   if (info == 0 && !c->has_comm() && d->covfac.p && covfac_enabled()) {
     if ((rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
@@ -1154,7 +1159,10 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
     d->pre0_key[1] = h_theta0[1];
     d->pre0_key[2] = pen_m;
   }
-  if (int rc = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr)) return rc;
+  d->cpack_early = !common_hp;
+  const int rc_e = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr);
+  d->cpack_early = false;
+  if (rc_e) return rc_e;
   if (info != 0) {
     std::string extra;
     if (info == 999 || info == -999) {  // the tile-graph inverse gave up on a flag: say which
