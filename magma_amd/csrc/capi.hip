@@ -96,7 +96,7 @@ static int check_small(int M, int nmax) {
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
                      void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
-                     const double* cov_fac, bool have_inverse) {
+                     const double* cov_fac, bool have_inverse, double* h_defer4) {
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = ((N + 63) / 64) * 64;
   Work wk(work, Np);
@@ -133,6 +133,9 @@ int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, do
                                   want_grad, wk.scal + 8, st)))
     return rc;
   if (sh && want_grad && (rc = sh->allreduce(sh->user, wk.scal + 9, 2, st))) return rc;
+  if (h_defer4 != nullptr)
+    return check_hip(hipMemcpyAsync(h_defer4, wk.scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st),
+                     "theta0_eval copy");
   double h4[4] = {0.0, 0.0, 0.0, 0.0};
   MAGMA_CHECK_HIP(hipMemcpyAsync(h4, wk.scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
   MAGMA_CHECK_HIP(hipStreamSynchronize(st));

@@ -20,7 +20,10 @@ struct Theta0Shard {
 int theta0_eval_impl(int N, const double* grid, double theta1, double theta2, double pen_diag,
                      const double* mean, const double* m0, const double* cov, int want_grad,
                      void* work, double* h_out3, int* h_info, hipStream_t st, const Theta0Shard* sh,
-                     const double* cov_fac = nullptr, bool have_inverse = false);
+                     const double* cov_fac = nullptr, bool have_inverse = false,
+                     double* h_defer4 = nullptr);
+// h_defer4 (optional, pinned host memory): (f, g1, g2, info) are copied there asynchronously and
+// the call returns without waiting; the caller synchronises st before reading them.
 // K_0(theta, pen_diag)^-1, log|K_0| and info into `work`, asynchronously on st, with dag_grid
 // workgroups for the tile-graph inverse (0 = default): the first evaluation of a theta_0 M-step
 // needs nothing from the E-step for this part, so the driver starts it next to the E-step's own

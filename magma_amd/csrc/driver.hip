@@ -153,6 +153,11 @@ struct magma_dataset {
   int nplist = 0;
   bool cpack_ok = false, have_order = false;
   bool cpack_early = false;  // set by magma_em_iteration around its E-step
+  bool theta_from_estep = false;  // d->theta holds the theta_i rows magma_em_iteration's E-step uploaded
+  std::vector<double> h_m0_last;  // last prior mean uploaded (set_m0)
+  double* h_mon = nullptr;        // pinned: (f, g1, g2, info) of a deferred theta_0 evaluation
+  int* h_flag = nullptr;          // pinned: per-individual info of the last E-step, counted lazily
+  bool flag_pending = false;
   // identical timestamps for all of this rank's individuals (CF:221-224, 347-350): with common
   // hyper-parameters their summed objective is M x one pseudo-individual's (small.hip, dedup_*)
   bool common_times = false, dedup_ok = false;
@@ -174,6 +179,8 @@ struct magma_dataset {
     if (pre_ev) (void)hipEventDestroy(pre_ev);
     if (pre0_ev) (void)hipEventDestroy(pre0_ev);
     if (h_rres) (void)hipHostFree(h_rres);
+    if (h_mon) (void)hipHostFree(h_mon);
+    if (h_flag) (void)hipHostFree(h_flag);
   }
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
   bool a0_valid = false;
@@ -341,6 +348,8 @@ int set_m0(magma_dataset* d, const double* h_m0, int n_m0, hipStream_t st) {
   std::vector<double> v((size_t)d->Np, 0.0);
   if (n_m0 != 1 && n_m0 != d->N) return fail(2, "m_0 must be a scalar or one value per grid point");
   for (int k = 0; k < d->N; ++k) v[(size_t)k] = n_m0 == 1 ? h_m0[0] : h_m0[k];
+  if (v == d->h_m0_last) return 0;  // (every E-step of a fit passes the same prior mean)
+  d->h_m0_last = v;
   MAGMA_CHECK_HIP(hipMemcpyAsync(d->m0.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
   return sync(st);  // v goes out of scope
 }
@@ -350,6 +359,17 @@ double mean_sigma(const magma_dataset* d, const double* th, int stride, double s
   double s = 0.0;
   for (int64_t i = 0; i < d->M_total; ++i) s += scale * th[3 * i + 2];
   return s / (double)d->M_total;
+}
+
+// the per-individual info words of the last E-step, copied to pinned memory on st: counted once st
+// has been synchronised (do_sync = false: the caller just did)
+int count_flagged(magma_dataset* d, hipStream_t st, bool do_sync = true) {
+  if (!d->flag_pending) return 0;
+  if (do_sync)
+    if (int rc = sync(st)) return rc;
+  for (int64_t k = 0; k < d->M; ++k) d->stats.flagged += (d->h_flag[k] != 0);
+  d->flag_pending = false;
+  return 0;
 }
 
 int ensure_cpack(magma_dataset* d, hipStream_t st) {
@@ -795,6 +815,10 @@ int magma_set_m0(magma_ctx* c, magma_dataset* d, const double* h_m0, int n_m0) {
 
 int magma_get_stats(const magma_dataset* d, magma_em_stats* out, int reset) {
   if (!d || !out) return fail(2, "get_stats: NULL argument");
+  if (d->flag_pending) {  // (an EM iteration that ended between its E-step and M-step)
+    magma_dataset* dd = const_cast<magma_dataset*>(d);
+    if (int rc = count_flagged(dd, dd->ctx->main)) return rc;
+  }
   *out = d->stats;
   if (reset) const_cast<magma_dataset*>(d)->stats = magma_em_stats{0, 0, 0, 0, 0};
   return 0;
@@ -895,10 +919,12 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     d->covfac_ok = true;
   }
   if (d->M > 0) {  // individuals whose K_i was not positive definite (they contributed nothing)
-    std::vector<int> hi((size_t)d->M);
-    MAGMA_CHECK_HIP(hipMemcpyAsync(hi.data(), d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
-    if ((rc = sync(st))) return rc;
-    for (int v : hi) d->stats.flagged += (v != 0);
+    if (!d->h_flag)
+      MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_flag, sizeof(int) * (size_t)d->M, hipHostMallocDefault));
+    MAGMA_CHECK_HIP(hipMemcpyAsync(d->h_flag, d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
+    d->flag_pending = true;
+    // (inside an EM iteration the M-step's first synchronisation of this stream counts them)
+    if (!d->cpack_early && (rc = count_flagged(d, st))) return rc;
   }
   if (h_info) *h_info = info;
   if (h_f0) *h_f0 = f0;
@@ -972,6 +998,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   if (overlap) {
     // both streams read the hyper-posterior the E-step left on the main stream
     if (int rc = sync(st)) return rc;
+    if (int rc = count_flagged(d, st, false)) return rc;
     const bool split = !common_hp && c->reserve_cus > 0 && M > 0;
     set_resident_max_workgroups(split ? std::max(1, c->ncu - c->reserve_cus) : 0);
     th0 = std::thread(run0);
@@ -1022,7 +1049,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
       do {
         HT("m: sync + thread start");
         if ((rc = ensure_cpack(d, st))) break;
-        if ((rc = set_theta(d, h_theta_i, 3, st))) break;
+        if (!d->theta_from_estep && (rc = set_theta(d, h_theta_i, 3, st))) break;
         HT("m: cpack + theta");
         const int* order = nullptr;
         // longest chains of the previous call first (they tend to stay the longest); the
@@ -1163,6 +1190,7 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   const int rc_e = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr);
   d->cpack_early = false;
   if (rc_e) return rc_e;
+  d->theta_from_estep = !common_hp && d->large.empty();  // (same h_theta_i: the M-step need not upload it again)
   if (info != 0) {
     std::string extra;
     if (info == 999 || info == -999) {  // the tile-graph inverse gave up on a flag: say which
@@ -1175,8 +1203,9 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
     return fail(5, std::string("E-step: ") + (info > 0 ? "K_0" : "hyper-posterior precision") +
                        " not positive definite (info=" + std::to_string(info) + ")" + extra);
   }
-  if (int rc = magma_m_step(c, d, h_theta0, h_theta_i, common_hp, opt4, h_theta0_out, h_theta_i_out))
-    return rc;
+  const int rc_m = magma_m_step(c, d, h_theta0, h_theta_i, common_hp, opt4, h_theta0_out, h_theta_i_out);
+  d->theta_from_estep = false;
+  if (rc_m) return rc_m;
   bool bad = std::isnan(h_theta0_out[0]) || std::isnan(h_theta0_out[1]);
   for (int64_t k = 0; k < 3 * d->M_total && !bad; ++k) bad = std::isnan(h_theta_i_out[k]);
   if (bad) {  // MG:46-51
@@ -1189,14 +1218,29 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   // values; only the theta_0 term needs an evaluation, which leaves K_0^-1 for the next E-step.
   h_logl2[0] = -d->last_f0 - d->last_sum_fi;
   HT("em: nan scan");
-  if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) return rc;
-  HT("em: prefetch launch");
+  // the monitoring evaluation is queued first and waited for last: the host work of the next
+  // E-step's sums (queued on the side stream) runs under it
   const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
-  double ll0 = 0.0;
-  if (d->pre_issued && c->monitor_wgs > 0) set_dag_grid_once(c->monitor_wgs);
-  const int rc_mon = theta0_f(c, d, h_theta0_out, sig, &ll0);
+  if (!d->h_mon) MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_mon, 4 * sizeof(double), hipHostMallocDefault));
+  const bool will_prefetch = d->M > 0 && prefetch_enabled();
+  if (will_prefetch && c->monitor_wgs > 0) set_dag_grid_once(c->monitor_wgs);
+  d->stats.theta0_evals += 1;
+  d->a0_valid = false;
+  const int rc_mon = theta0_eval_impl(d->N, d->grid.as<double>(), h_theta0_out[0], h_theta0_out[1], sig,
+                                      d->mean.as<double>(), d->m0.as<double>(), d->P.as<double>(), 0,
+                                      d->work.p, nullptr, nullptr, c->main, nullptr, nullptr, false, d->h_mon);
   set_dag_grid_once(0);
   if (rc_mon) return rc_mon;
+  HT("em: monitoring launch");
+  if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) return rc;
+  HT("em: prefetch launch");
+  if (int rc = sync(c->main)) return rc;
+  const int info_mon = (int)d->h_mon[3];
+  d->a0_valid = (info_mon == 0);
+  d->a0_key[0] = h_theta0_out[0];
+  d->a0_key[1] = h_theta0_out[1];
+  d->a0_key[2] = sig;
+  const double ll0 = info_mon == 0 ? d->h_mon[0] : nanv;
   h_logl2[1] = -ll0 - d->last_sum_fi_new;
   HT("em: monitoring (sync)");
   return 0;
