@@ -288,6 +288,7 @@ def main():
 
     if rank == 0:
         N, n, Mloc = cfg["N"], cfg["n"], eng.hi - eng.lo
+        covfac = world == 1 and "cov_factor=0" not in os.environ.get("MAGMA_OPTIONS", "").replace(" ", "")
         units = M_total / 10000.0 if args.config == "c3" else 1.0
         value = n_steps * units / elapsed
         S2 = Mloc * n ** 2
@@ -296,7 +297,9 @@ def main():
         # MI355X, so the per-individual FP64 kernels are priced against the same 78.6 TFLOP/s
         alg = {
             # (with several ranks each forms its share of the block rows: priced on what runs)
-            "gemm_nt(T=Kinv*C)": ("mfma", 2.0 * N ** 3 / world, True),
+            # one rank: Y = K^-1 V' with the triangular factor of cov (N^3 executed, the default);
+            # several ranks or cov_factor=0: the full product T = K^-1 C (2 N^3, split over ranks)
+            "gemm_nt(T=Kinv*C)": ("mfma", (1.0 if covfac else 2.0) * N ** 3 / world, True),
             # Z = T K^-1 is symmetric: only its lower tiles are formed (N^3 executed of the 2 N^3
             # a full product would take); priced on what runs
             "theta0_contract": ("mfma", 1.0 * N ** 3 / world, False),
