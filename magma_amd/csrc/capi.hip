@@ -621,6 +621,11 @@ int magma_set_option(const char* name, long value) {
     set_dag_workgroups((int)value);
     return 0;
   }
+  if (std::string(name) == "dag_max_block_rows") {  // (64: above it the launch-per-step path wins)
+    if (value < 0 || value > 256) return fail(2, "dag_max_block_rows must be in 0..256");
+    set_dag_max_block_rows((int)value);
+    return 0;
+  }
   if (std::string(name) == "dag_walker") {  // one workgroup walks the chain of diagonal tiles
     set_dag_walker((int)value);
     return 0;

@@ -62,6 +62,7 @@ int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* wor
 bool spd_inverse_dag_supported(int Np);
 void set_dag_workgroups(int v);
 void set_dag_walker(int v);
+void set_dag_max_block_rows(int v);  // the one-launch inverse is used up to this many block rows
 void set_dag_grid_once(int v);  // this thread's next tile-graph launch only
 void set_dag_stamps(void* p);  // diagnostic builds only (-DMAGMA_DAG_STAMPS)
 int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double* work,
