@@ -1049,6 +1049,17 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void dag_init_kernel(int* __restrict__ ctrl, int nwords,
+                                                        double* __restrict__ logdet,
+                                                        int* __restrict__ info) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < nwords) ctrl[k] = 0;
+  if (k == 0) {
+    *logdet = 0.0;
+    *info = 0;
+  }
+}
+
 size_t spd_inverse_dag_ctrl_bytes(int nt) {
   return (((size_t)(8 + 2 * nt * nt + 2 * nt) * sizeof(int)) + 255) & ~(size_t)255;
 }
@@ -1097,9 +1108,10 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   a.ld = Np;
   if (spd_inverse_dag_ctrl_bytes(nt) > n2 * sizeof(double))
     return fail(2, "spd_inverse: workspace too small for the control block");
-  MAGMA_CHECK_HIP(hipMemsetAsync(ctrl, 0, spd_inverse_dag_ctrl_bytes(nt), st));
-  MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
-  MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+  // control block, log-det and info cleared by one small kernel (three memsets cost three
+  // launches in front of every inverse of the serial theta_0 chain)
+  const int nwords = (int)(spd_inverse_dag_ctrl_bytes(nt) / sizeof(int));
+  hipLaunchKernelGGL(dag_init_kernel, dim3((nwords + 255) / 256), dim3(256), 0, st, ctrl, nwords, logdet, info);
   const int total = nt * nt + nt * (nt + 1) / 2;
   // (walker mode: one more workgroup -- whichever starts first walks the diagonal chain)
   const int want = t_dag_grid_once > 0 ? t_dag_grid_once : g_dag_workgroups;
