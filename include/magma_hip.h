@@ -66,7 +66,15 @@ int magma_prof_reset(void);
  * a cap of G leaves the other compute units to the kernels of other streams -- the theta_0
  * chain). "dag_workgroups": workgroups of the one-launch dense inverse (0 = launch-per-step
  * path). "dedup" (default 1): with identical timestamps and common hyper-parameters the driver
- * inverts K once per evaluation (Computing_functions.R:221-224, 347-350); 0 = batched sum. */
+ * inverts K once per evaluation (Computing_functions.R:221-224, 347-350); 0 = batched sum.
+ * "dag_walker" (default 2): who walks the chain of diagonal tiles of the one-launch inverse -- 2: one
+ * workgroup whose wavefronts work a block step ahead of the 64 x 64 factor, 1: one workgroup in
+ * lock step, 0: a task per block step. "dag_max_block_rows" (default 64): the one-launch inverse
+ * is used up to this many 64-row blocks. Driver switches (default 1): "prefactor" (the M-step's
+ * first K_0 inverse started next to the E-step's), "prefetch" (the next E-step's sums started
+ * under the monitoring call), "cov_factor" (theta_0 gradient through the E-step's triangular
+ * factor of cov; one rank). Results do not depend on any of them except "dag_walker" and
+ * "cov_factor" (summation order: last bits). */
 int magma_set_option(const char* name, long value);
 int magma_prof_get(int id, int* h_count, double* h_total_ms);
 
