@@ -126,7 +126,7 @@ template <bool SELF>
 __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
                                            unsigned offB, const int* fB, int k0, int k1, int ld,
                                            TileAcc& acc, TileAcc& accS, double* As, double* Bs,
-                                           int* ctrl, int* s_ready) {
+                                           double* S2, int* ctrl, int* s_ready) {
   if (k0 >= k1) return true;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -148,38 +148,53 @@ __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* 
     }
   };
   fetch(k0);
+  // two slab buffers (the second pair in S2, LDS the tile tasks do not otherwise use): slab s + 1
+  // is written while slab s is multiplied, one barrier per slab instead of two
+  double* Ab[2] = {As, S2};
+  double* Bb[2] = {Bs, S2 + 16 * TLD};
 #pragma unroll 1
   for (int k = k0; k < k1; ++k) {
     const bool more = k + 1 < k1;
     const bool pf = more && (k + 1) < ready;
+    __syncthreads();  // both buffers free (the previous tile's last slabs have been read)
+    *reinterpret_cast<v4u*>(&Ab[0][kr * TLD + x4]) = ta[0][0];
+    *reinterpret_cast<v4u*>(&Ab[0][kr * TLD + x4 + 2]) = ta[0][1];
+    *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4]) = tb[0][0];
+    *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4 + 2]) = tb[0][1];
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      __syncthreads();
-      *reinterpret_cast<v4u*>(&As[kr * TLD + x4]) = ta[s][0];
-      *reinterpret_cast<v4u*>(&As[kr * TLD + x4 + 2]) = ta[s][1];
-      *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4]) = tb[s][0];
-      *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4 + 2]) = tb[s][1];
-      __syncthreads();
+      if (s + 1 < 4) {
+        double* An = Ab[(s + 1) & 1];
+        double* Bn = Bb[(s + 1) & 1];
+        *reinterpret_cast<v4u*>(&An[kr * TLD + x4]) = ta[s + 1][0];
+        *reinterpret_cast<v4u*>(&An[kr * TLD + x4 + 2]) = ta[s + 1][1];
+        *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4]) = tb[s + 1][0];
+        *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4 + 2]) = tb[s + 1][1];
+      }
       if (s == 3 && pf) fetch(k + 1);
+      const double* Ac = Ab[s & 1];
+      const double* Bc = Bb[s & 1];
 #pragma unroll
       for (int kk = 0; kk < 16; kk += 4) {
-        const double fa0 = As[kk * TLD + fo + wm * 32];
-        const double fa1 = As[kk * TLD + fo + wm * 32 + 16];
-        const double fb0 = Bs[kk * TLD + fo + wn * 32];
-        const double fb1 = Bs[kk * TLD + fo + wn * 32 + 16];
+        const double fa0 = Ac[kk * TLD + fo + wm * 32];
+        const double fa1 = Ac[kk * TLD + fo + wm * 32 + 16];
+        const double fb0 = Bc[kk * TLD + fo + wn * 32];
+        const double fb1 = Bc[kk * TLD + fo + wn * 32 + 16];
         acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
         acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
         acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
         acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
         if constexpr (SELF) {
-          const double fs0 = As[kk * TLD + fo + wn * 32];
-          const double fs1 = As[kk * TLD + fo + wn * 32 + 16];
+          const double fs0 = Ac[kk * TLD + fo + wn * 32];
+          const double fs1 = Ac[kk * TLD + fo + wn * 32 + 16];
           accS.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa0, accS.c[0][0], 0, 0, 0);
           accS.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa1, accS.c[0][1], 0, 0, 0);
           accS.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa0, accS.c[1][0], 0, 0, 0);
           accS.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa1, accS.c[1][1], 0, 0, 0);
         }
       }
+      if (s + 1 < 4) __syncthreads();
     }
     if (more && !pf) {
       ready = poll_ready(fA, fB, k + 1, k1, ctrl, s_ready);
@@ -192,9 +207,9 @@ __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* 
 
 __device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA, rsrc_t rb,
                                          unsigned offB, const int* fB, int k0, int k1, int ld,
-                                         TileAcc& acc, double* As, double* Bs, int* ctrl,
+                                         TileAcc& acc, double* As, double* Bs, double* S2, int* ctrl,
                                          int* s_ready) {
-  return acc_rows_t<false>(ra, offA, fA, rb, offB, fB, k0, k1, ld, acc, acc, As, Bs, ctrl, s_ready);
+  return acc_rows_t<false>(ra, offA, fA, rb, offB, fB, k0, k1, ld, acc, acc, As, Bs, S2, ctrl, s_ready);
 }
 
 // out(m, n) = sum_k V(m, k) X(n, k): V staged in LDS as Vs[k * TLD + m] (64 rows of TLD), X = the
@@ -829,7 +844,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       while ((i + 1) * (i + 2) / 2 <= p) ++i;
       const int j = p - i * (i + 1) / 2;
       if (!acc_rows(rU, (unsigned)i * NB, a.fU + i * nt, rU, (unsigned)j * NB, a.fU + j * nt, i, nt,
-                    ld, acc, As, Bs, a.ctrl, &s_ready))
+                    ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
         return abandon(a.info);
       double* C = a.Aout + (int64_t)i * NB + (int64_t)j * NB * ld;
       double* Ct = a.Aout + (int64_t)j * NB + (int64_t)i * NB * ld;
@@ -849,7 +864,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       // does not, has a task of its own (HS below) and half the MFMAs are gone from this one.
       tile_load_neg(acc, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
       if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB, a.fL + (j - 1) * nt,
-                    0, j - 1, ld, acc, As, Bs, a.ctrl, &s_ready))
+                    0, j - 1, ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
         return abandon(a.info);
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Ws[n * TLD + m] = -v; });
@@ -865,7 +880,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       const int i = j + 1;
       tile_load_neg(acc, a.A + (int64_t)i * NB * (ld + 1), ld);
       if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)i * NB, a.fL + i * nt, 0, j, ld,
-                    acc, As, Bs, a.ctrl, &s_ready))
+                    acc, As, Bs, Ss, a.ctrl, &s_ready))
         return abandon(a.info);
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
@@ -883,7 +898,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       if (j > 0) {
         tile_load_neg(accB, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
         if (!acc_rows_t<true>(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB,
-                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, a.ctrl,
+                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, Ss, a.ctrl,
                               &s_ready))
           return abandon(a.info);
       }
@@ -909,7 +924,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
         TileAcc accB;
         tile_load_neg(accB, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
         if (!acc_rows_t<true>(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB,
-                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, a.ctrl,
+                              a.fL + (j - 1) * nt, 0, j - 1, ld, accB, acc, As, Bs, Ss, a.ctrl,
                               &s_ready))
           return abandon(a.info);
         // parked in LDS as the operand of the product with X^T
@@ -1013,7 +1028,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       const int i = j + r;
       tile_load_neg(acc, a.A + (int64_t)i * NB + (int64_t)j * NB * ld, ld);
       if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)j * NB, a.fL + j * nt, 0, j,
-                    ld, acc, As, Bs, a.ctrl, &s_ready))
+                    ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
         return abandon(a.info);
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
@@ -1024,7 +1039,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       // ---- T(c,j), c < j
       const int c = r - (nt - j);
       if (!acc_rows(rU, (unsigned)c * NB, a.fU + c * nt, rL, (unsigned)j * NB, a.fL + j * nt, c, j,
-                    ld, acc, As, Bs, a.ctrl, &s_ready))
+                    ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
         return abandon(a.info);
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
