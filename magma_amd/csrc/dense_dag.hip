@@ -215,7 +215,7 @@ __device__ __forceinline__ bool acc_rows(rsrc_t ra, unsigned offA, const int* fA
 // out(m, n) = sum_k V(m, k) X(n, k): V staged in LDS as Vs[k * TLD + m] (64 rows of TLD), X = the
 // 64 x 64 tile at element offset offX of rx (column-major, ld), published behind flag fX.
 __device__ __forceinline__ bool times_xt(const double* Vs, rsrc_t rx, unsigned offX, const int* fX,
-                                         int ld, TileAcc& out, double* Bs, int* ctrl,
+                                         int ld, TileAcc& out, double* Bs, double* B2, int* ctrl,
                                          int* s_ready, long long* stamp2) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -233,24 +233,31 @@ __device__ __forceinline__ bool times_xt(const double* Vs, rsrc_t rx, unsigned o
     tb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, ob, 0, AUX_SC1);
     tb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, ob + 16u, 0, AUX_SC1);
   }
+  double* Bb[2] = {Bs, B2};  // slab s + 1 is written while slab s is multiplied (see acc_rows_t)
+  __syncthreads();
+  *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4]) = tb[0][0];
+  *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4 + 2]) = tb[0][1];
+  __syncthreads();
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    __syncthreads();
-    *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4]) = tb[s][0];
-    *reinterpret_cast<v4u*>(&Bs[kr * TLD + x4 + 2]) = tb[s][1];
-    __syncthreads();
+    if (s + 1 < 4) {
+      *reinterpret_cast<v4u*>(&Bb[(s + 1) & 1][kr * TLD + x4]) = tb[s + 1][0];
+      *reinterpret_cast<v4u*>(&Bb[(s + 1) & 1][kr * TLD + x4 + 2]) = tb[s + 1][1];
+    }
     const double* Va = Vs + 16 * s * TLD;
+    const double* Bc = Bb[s & 1];
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
       const double fa0 = Va[kk * TLD + fo + wm * 32];
       const double fa1 = Va[kk * TLD + fo + wm * 32 + 16];
-      const double fb0 = Bs[kk * TLD + fo + wn * 32];
-      const double fb1 = Bs[kk * TLD + fo + wn * 32 + 16];
+      const double fb0 = Bc[kk * TLD + fo + wn * 32];
+      const double fb1 = Bc[kk * TLD + fo + wn * 32 + 16];
       out.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, out.c[0][0], 0, 0, 0);
       out.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, out.c[0][1], 0, 0, 0);
       out.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, out.c[1][0], 0, 0, 0);
       out.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, out.c[1][1], 0, 0, 0);
     }
+    if (s + 1 < 4) __syncthreads();
   }
   return true;
 }
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
         TileAcc out;
         tile_zero(out);
         if (!times_xt(Vs, rL, (unsigned)(j - 1) * NB * (unsigned)(ld + 1),
-                      a.fL + (j - 1) * nt + (j - 1), ld, out, Bs, a.ctrl, &s_ready, nullptr))
+                      a.fL + (j - 1) * nt + (j - 1), ld, out, Bs, Ss, a.ctrl, &s_ready, nullptr))
           return abandon(a.info);
         __syncthreads();  // every wavefront has read Vs
         tile_foreach(out, [&](int m, int n, double v) { Vs[n * TLD + m] = v; });
@@ -1050,7 +1057,7 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
     DAG_STAMP(t, 1);
     TileAcc out;
     tile_zero(out);
-    if (!times_xt(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), a.fL + j * nt + j, ld, out, Bs,
+    if (!times_xt(Vs, rL, (unsigned)j * NB * (unsigned)(ld + 1), a.fL + j * nt + j, ld, out, Bs, Ss,
                   a.ctrl, &s_ready, a.stamps ? a.stamps + t * 8 + 2 : nullptr))
       return abandon(a.info);
     DAG_STAMP(t, 3);
