@@ -640,7 +640,8 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
             __builtin_memcpy(&xv, &x, 8);
             __builtin_amdgcn_raw_buffer_store_b64(
                 xv, rU, (offD + (unsigned)cc + (unsigned)rr * (unsigned)ld) * 8u, 0, AUX_SC1);
-            if (jt == 3) lds_publish(sy + WS_XROW, 16 * j + b + 1);
+            // (announced per batch of 16 rows: the release fence in front of it is a stall)
+            if (jt == 3 && (b & 3) == 3) lds_publish(sy + WS_XROW, 16 * j + b + 1);
           });
       if (ok) {
         if (lane == 0) {
