@@ -385,6 +385,9 @@ int magma_copy_unpad(int N, const double* src, double* dst, int64_t ld_dst, void
  * depends on LDS it never wrote shows up as a NaN in the parity tests instead of once in a
  * while. Synchronises. */
 int magma_debug_poison_lds(void* stream);
+/* Diagnostic words of the device-resident M-step (24 x uint64; word 0 != 0: a workgroup gave up on
+ * a wait between its wavefronts, see small.hip). No counterpart in the reference. */
+int magma_debug_resident_diag(unsigned long long* h24);
 
 /* ---- batched L-BFGS-B driver (host side, reverse communication) ----
  * Stands in for `optimr::opm(method = "L-BFGS-B")` -> stats::optim (CF:412-413, 417-418,

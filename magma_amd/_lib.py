@@ -55,6 +55,7 @@ SIGNATURES = {
                                 C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i),
                                 C.POINTER(_i), C.POINTER(_i), _p]),
     "magma_debug_poison_lds": (_i, [_p]),
+    "magma_debug_resident_diag": (_i, [_p]),
     "magma_sum": (_i, [_i64, _p, _p, C.POINTER(_d), _p]),
     "magma_pred_gp": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "magma_pred_gp_batched": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i,

@@ -616,6 +616,10 @@ int magma_set_option(const char* name, long value) {
     set_resident_max_workgroups((int)value);
     return 0;
   }
+  if (std::string(name) == "resident_help") {  // idle wavefronts take column blocks of running ones
+    set_resident_help((int)value);
+    return 0;
+  }
   if (std::string(name) == "dag_workgroups") {
     if (value < 0 || value > 4096) return fail(2, "dag_workgroups must be in 0..4096");
     set_dag_workgroups((int)value);
@@ -665,6 +669,8 @@ int magma_theta0_mstep(int N, const double* grid, const double* h_theta0, double
   return theta0_mstep_impl(N, grid, h_theta0, pen_diag, mean, m0, cov, m, factr, pgtol, maxit, work,
                            h_theta_out, h_f_out, h_f_x0, h_iters, h_nfev, h_status, S(stream), nullptr);
 }
+
+int magma_debug_resident_diag(unsigned long long* h24) { return magma::resident_diag_read(h24); }
 
 int magma_debug_poison_lds(void* stream) {
   double* sink = nullptr;

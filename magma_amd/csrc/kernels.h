@@ -25,6 +25,8 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
                        double* theta_out, double* f_out, double* fx0_out, int* iters, int* nfev,
                        int* status, hipStream_t st);
 void set_resident_max_workgroups(int v);
+void set_resident_help(int v);
+int resident_diag_read(unsigned long long* h24);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
                             const double* cov, int64_t ldc, double* cpack, hipStream_t st);
 // solve() / ginv() slow path for the individuals whose info != 0 (see small.hip)

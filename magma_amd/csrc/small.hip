@@ -24,6 +24,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 namespace magma {
 
@@ -656,29 +657,24 @@ __global__ __launch_bounds__(256) void update_inv_kernel(
 //  4. T = C K^-1: A fragments straight from the packed C in global memory, B from Ks.
 //  5. Z = K^-1 T: A fragments from Ks, B fragments = T's registers; only tiles on or below the
 //     diagonal, each contracted with K_nl and dK/dtheta2 as soon as it is complete.
-// One evaluation at hyper-parameters (th1, th2, sigma) by this wavefront. tbuf / zbuf hold the
-// individual's timestamps and residuals y - mean (zero beyond n), abuf and Ks are scratch; every
-// lane returns the same f_res, g_res (only with want_grad), info_res.
+// The evaluation comes in pieces so that the device-resident M-step can hand the column blocks of
+// stages 4 / 5 to other wavefronts of its workgroup (indiv_mstep_kernel); indiv_eval_body below
+// strings them together for one wavefront.
+//
+// Stages 1-3: K(theta) (+ C in mode 1) -> K^-1 in Ks (LDS), log|K|, info. Ends with a wave_sync().
 template <int NMAX>
-__device__ __forceinline__ void indiv_eval_body(
-    int lane, int n, int i, double th1, double th2, double sigma, const double* tbuf,
-    const double* zbuf, double* abuf, double* Ks, const double* __restrict__ cpack, int mode,
-    int want_grad, double& f_res, double (&g_res)[3], int& info_res) {
+__device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEParams& p,
+                                            const double* tbuf, double* Ks,
+                                            const double* __restrict__ cpack, int mode,
+                                            double& logdet, int& info_res) {
   constexpr int NT = (NMAX + 15) / 16;  // 16 x 16 tiles per dimension
   constexpr int NK = NMAX / 4;          // blocks of 4 rows / k-blocks
   constexpr int LD = NMAX;              // row length of Ks
   static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
   const int l = lane & 15, g = lane >> 4;
-  const SEParams p = se_params(th1, th2, sigma);
-  const double zr = zbuf[lane];
-  STAMP_INIT();
   const bool have_c = (cpack != nullptr);
   // packed C_i: Cq[kk * 64 * NT + it] = C[16 it + l][4 kk + g] (see indiv_gather_cov_kernel)
   const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
-  const bool with_c = (mode == 0 && have_c);
-  // The packed C_i is requested as one batch of 16-byte loads (26 per lane at NMAX = 52) well
-  // before its first use: issued a pair at a time next to their uses, which is what the
-  // compiler does when left alone, they cost NK serial HBM latencies per wavefront.
 
   // ---- 1. K in accumulator layout (rows >= NMAX are never touched: compile-time skip)
   v4d A[NT][NT];
@@ -747,15 +743,13 @@ __device__ __forceinline__ void indiv_eval_body(
         A[it][jt][v] = (r < n && c < n) ? A[it][jt][v] * sc : ((r == c) ? 1.0 : 0.0);
       }
     }
-  STAMP(0);
 
   // ---- 2. blocked symmetric sweep (mfma_sweep.h)
   double pm = 1.0;
   int pe = 0, info = 0;
   mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
-  const double logdet =
-      log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
-  STAMP(1);
+  logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
+  info_res = info;
 
   // ---- 3. K^-1 = -A to LDS
 #pragma unroll
@@ -771,38 +765,176 @@ __device__ __forceinline__ void indiv_eval_body(
       }
     }
   wave_sync();
-  STAMP(4);
+}
 
-  // The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52), issued once the
-  // accumulator tiles are dead and consumed after alpha. (Left alone the compiler issues them a
-  // pair at a time next to their uses: NK serial HBM latencies per wavefront.)
+// The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52). (Left alone the compiler
+// issues them a pair at a time next to their uses: NK serial HBM latencies per wavefront; callers
+// put a sched_barrier on either side.)
+template <int NMAX>
+__device__ __forceinline__ void eval_load_c(double (&cf)[NMAX / 4][(NMAX + 15) / 16],
+                                            const double* __restrict__ cpack, int i, int lane) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int it = 0; it < NT; ++it) cf[kk][it] = Cq[kk * 64 * NT + it];
+}
+
+// alpha = K^-1 z (lane r owns row r; column reads by symmetry); zero beyond NMAX.
+template <int NMAX>
+__device__ __forceinline__ double eval_alpha(int lane, const double* Ks, const double* zbuf) {
+  constexpr int LD = NMAX;
+  double alpha = 0.0;
+  const int lr = lane < NMAX ? lane : 0;
+#pragma unroll
+  for (int c = 0; c < NMAX; c += 2) {
+    const double2 zz = *reinterpret_cast<const double2*>(&zbuf[c]);
+    alpha = fma(Ks[c * LD + lr], zz.x, alpha);
+    alpha = fma(Ks[(c + 1) * LD + lr], zz.y, alpha);
+  }
+  return lane < NMAX ? alpha : 0.0;
+}
+
+// Stages 4 / 5 for column block JT: Tc = (C K^-1)[:, JT] (NT tiles), then Z[at][JT] = K^-1 Tc for
+// at >= JT, contracted at once with K_nl and dK/dtheta2. Returns THIS block's sums per lane,
+// started from zero: the caller adds the blocks in the order 0, 1, ..., whoever computed them, so
+// that every route gives the same bits. alpha (abuf) is first read after the products:
+// wait_alpha() is called in front of that read (a helper wavefront waits there for the owner).
+template <int NMAX, int JT, class WaitAlpha>
+__device__ __forceinline__ void eval_block(int lane, int n, const SEParams& p, bool with_c,
+                                           const double (&cf)[NMAX / 4][(NMAX + 15) / 16],
+                                           const double* Ks, const double* tbuf, const double* abuf,
+                                           WaitAlpha&& wait_alpha, double& s1, double& s2,
+                                           double& s3, double& cor) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4, LD = NMAX;
+  constexpr int jt = JT;
+  const int l = lane & 15, g = lane >> 4;
+  s1 = 0.0;
+  s2 = 0.0;
+  s3 = 0.0;
+  cor = 0.0;
+  v4d Tc[NT];
+  v4d Z[NT];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    Tc[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+    Z[it] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  if (with_c) {
+    double bf = Ks[g * LD + 16 * jt + l];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const double b0 = bf;
+      if (kk + 1 < NK) bf = Ks[(4 * (kk + 1) + g) * LD + 16 * jt + l];
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+        Tc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[kk][it], b0, Tc[it], 0, 0, 0);
+    }
+    // tr(C K^-1): the diagonal of T sits in the diagonal tiles where g + 4v == l
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (16 * jt + 4 * v < NMAX) cor += (g + 4 * v == l) ? Tc[jt][v] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    double ka[NT];
+#pragma unroll
+    for (int at = jt; at < NT; ++at) ka[at] = Ks[g * LD + 16 * at + l];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      double k0[NT];
+#pragma unroll
+      for (int at = jt; at < NT; ++at) {
+        k0[at] = ka[at];
+        if (kk + 1 < NK) ka[at] = Ks[(4 * (kk + 1) + g) * LD + 16 * at + l];
+      }
+#pragma unroll
+      for (int at = jt; at < NT; ++at)
+        Z[at] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0[at], Tc[kk >> 2][kk & 3], Z[at], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  wait_alpha();
+  // element (ra, cj), ra = 16 at + 4v + g, cj = 16 jt + l
+  const int cj = 16 * jt + l;
+  const double acj = abuf[cj];
+  const double tcj = tbuf[cj];
+#pragma unroll
+  for (int at = jt; at < NT; ++at) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (16 * at + 4 * v >= NMAX) continue;
+      const int ra = 16 * at + 4 * v + g;
+      const bool ok = ra < n && cj < n;
+      const double d = tbuf[ra] - tcj;
+      const double gq = p.h * d * d;
+      double knl = exp(p.th1 - gq);
+      knl = (ra == cj) ? p.eth1 : knl;
+      const double W = fma(abuf[ra], acj, Z[at][v] - Ks[ra * LD + cj]);
+      const double wt = (jt == at) ? 1.0 : 2.0;  // tiles above the diagonal by symmetry
+      const double wk = ok ? wt * W * knl : 0.0;
+      s1 += wk;
+      s2 = fma(wk, gq, s2);  // dK/dtheta2 = gq * K_nl, zero on the diagonal (gq = 0 there)
+      s3 += (ok && ra == cj) ? W : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// f(std::integral_constant<int, jt>) for jt = 0 .. NT - 1, in order.
+template <int NMAX, int JT = 0, class F>
+__device__ __forceinline__ void for_blocks(F&& f) {
+  f(std::integral_constant<int, JT>{});
+  if constexpr (JT + 1 < (NMAX + 15) / 16) for_blocks<NMAX, JT + 1>(f);
+}
+
+// f and the gradient from the per-lane sums of all column blocks (every lane returns the same).
+__device__ __forceinline__ void eval_finish(int n, double sigma, double logdet, double ssq,
+                                            int info, bool with_c, double s1, double s2, double s3,
+                                            double cor, double& f_res, double (&g_res)[3]) {
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  if (with_c) cor = wave_sum(cor);
+  f_res = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  s3 = wave_sum(s3);
+  g_res[0] = (info == 0) ? -0.5 * s1 : nanv;
+  g_res[1] = (info == 0) ? -0.5 * s2 : nanv;
+  g_res[2] = (info == 0) ? -sigma * s3 : nanv;
+}
+
+// One evaluation at hyper-parameters (th1, th2, sigma) by this wavefront. tbuf / zbuf hold the
+// individual's timestamps and residuals y - mean (zero beyond n), abuf and Ks are scratch; every
+// lane returns the same f_res, g_res (only with want_grad), info_res.
+template <int NMAX>
+__device__ __forceinline__ void indiv_eval_body(
+    int lane, int n, int i, double th1, double th2, double sigma, const double* tbuf,
+    const double* zbuf, double* abuf, double* Ks, const double* __restrict__ cpack, int mode,
+    int want_grad, double& f_res, double (&g_res)[3], int& info_res) {
+  constexpr int NT = (NMAX + 15) / 16;
+  constexpr int NK = NMAX / 4;
+  constexpr int LD = NMAX;
+  const int l = lane & 15, g = lane >> 4;
+  const SEParams p = se_params(th1, th2, sigma);
+  const double zr = zbuf[lane];
+  STAMP_INIT();
+  const bool with_c = (mode == 0 && cpack != nullptr);
+  double logdet;
+  int info;
+  eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
+  STAMP(1);
+
+  // issued once the accumulator tiles are dead and consumed after alpha
   __builtin_amdgcn_sched_barrier(0);
   double cf[NK][NT];
-  if (with_c) {
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk)
-#pragma unroll
-      for (int it = 0; it < NT; ++it) cf[kk][it] = Cq[kk * 64 * NT + it];
-  }
+  if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
   __builtin_amdgcn_sched_barrier(0);
 
-  // alpha = K^-1 z ; ssq = z' alpha  (lane r owns row r; column reads by symmetry)
-  double alpha = 0.0;
-  {
-    const int lr = lane < NMAX ? lane : 0;
-#pragma unroll
-    for (int c = 0; c < NMAX; c += 2) {
-      const double2 zz = *reinterpret_cast<const double2*>(&zbuf[c]);
-      alpha = fma(Ks[c * LD + lr], zz.x, alpha);
-      alpha = fma(Ks[(c + 1) * LD + lr], zz.y, alpha);
-    }
-    alpha = lane < NMAX ? alpha : 0.0;
-  }
+  const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
   const double ssq = wave_sum(zr * alpha);
   STAMP(2);
 
-  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
   if (!want_grad) {
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     double cor = 0.0;
     if (with_c) {  // sum(K^-1 o C) in accumulator layout, C read by symmetry
 #pragma unroll
@@ -824,87 +956,20 @@ __device__ __forceinline__ void indiv_eval_body(
     return;
   }
   abuf[lane] = alpha;
-
-  // ---- 4./5. by column block jt: Tc = (C K^-1)[:, jt] (NT tiles), then Z[at][jt] = K^-1 Tc for
-  // at >= jt, contracted at once. Only cf (the packed C) stays live across blocks.
   wave_sync();  // abuf visible
-  double cor = 0.0;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt) {
-    v4d Tc[NT];
-    v4d Z[NT];
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-      Tc[it] = (v4d){0.0, 0.0, 0.0, 0.0};
-      Z[it] = (v4d){0.0, 0.0, 0.0, 0.0};
-    }
-    if (with_c) {
-      double bf = Ks[g * LD + 16 * jt + l];
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
-        const double b0 = bf;
-        if (kk + 1 < NK) bf = Ks[(4 * (kk + 1) + g) * LD + 16 * jt + l];
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-          Tc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[kk][it], b0, Tc[it], 0, 0, 0);
-      }
-      // tr(C K^-1): the diagonal of T sits in the diagonal tiles where g + 4v == l
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (16 * jt + 4 * v < NMAX) cor += (g + 4 * v == l) ? Tc[jt][v] : 0.0;
-      __builtin_amdgcn_sched_barrier(0);
-      double ka[NT];
-#pragma unroll
-      for (int at = jt; at < NT; ++at) ka[at] = Ks[g * LD + 16 * at + l];
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
-        double k0[NT];
-#pragma unroll
-        for (int at = jt; at < NT; ++at) {
-          k0[at] = ka[at];
-          if (kk + 1 < NK) ka[at] = Ks[(4 * (kk + 1) + g) * LD + 16 * at + l];
-        }
-#pragma unroll
-        for (int at = jt; at < NT; ++at)
-          Z[at] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0[at], Tc[kk >> 2][kk & 3], Z[at], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // element (ra, cj), ra = 16 at + 4v + g, cj = 16 jt + l
-    const int cj = 16 * jt + l;
-    const double acj = abuf[cj];
-#pragma unroll
-    for (int at = jt; at < NT; ++at) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (16 * at + 4 * v >= NMAX) continue;
-        const int ra = 16 * at + 4 * v + g;
-        const bool ok = ra < n && cj < n;
-        const double d = tbuf[ra] - tcol[jt];
-        const double gq = p.h * d * d;
-        double knl = exp(p.th1 - gq);
-        knl = (ra == cj) ? p.eth1 : knl;
-        const double W = fma(abuf[ra], acj, Z[at][v] - Ks[ra * LD + cj]);
-        const double wt = (jt == at) ? 1.0 : 2.0;  // tiles above the diagonal by symmetry
-        const double wk = ok ? wt * W * knl : 0.0;
-        s1 += wk;
-        s2 = fma(wk, gq, s2);  // dK/dtheta2 = gq * K_nl, zero on the diagonal (gq = 0 there)
-        s3 += (ok && ra == cj) ? W : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if (with_c) cor = wave_sum(cor);
-  f_res = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
-  info_res = info;
+
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0;
+  for_blocks<NMAX>([&](auto JT) {
+    double q1, q2, q3, qc;
+    eval_block<NMAX, decltype(JT)::value>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
+    s1 += q1;
+    s2 += q2;
+    s3 += q3;
+    cor += qc;
+  });
   STAMP(7);
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  s3 = wave_sum(s3);
-  g_res[0] = (info == 0) ? -0.5 * s1 : nanv;
-  g_res[1] = (info == 0) ? -0.5 * s2 : nanv;
-  g_res[2] = (info == 0) ? -sigma * s3 : nanv;
+  eval_finish(n, sigma, logdet, ssq, info, with_c, s1, s2, s3, cor, f_res, g_res);
+  info_res = info;
   STAMP(8);
   STAMP_FLUSH();
 }
@@ -974,33 +1039,195 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
 // one need (the workgroups of the dense inverse want a whole free compute unit; with
 // one-wavefront workgroups spread over every SIMD of the chip they waited for the launch to
 // drain). Individuals are handed out through a ticket counter in the order given (longest
-// expected chain first): a wavefront that finishes a problem takes the next ticket, so the launch
-// lasts max(longest chain, total work / wavefronts).
+// expected chain first): a wavefront that finishes a problem takes the next ticket.
+//
+// The tail. Which individuals need the long chains (100-200 evaluations against 5-8 on average)
+// is not known ahead, so the launch used to last as long as the longest chain on one wavefront
+// while the wavefronts next to it had nothing left to do. Now a wavefront that finds the tickets
+// gone becomes a HELPER of its workgroup. The owner of a running problem, once K^-1 is in its LDS
+// slice, opens its board: one claim word per column block of stages 4 / 5. Helpers and the owner
+// itself claim blocks (atomic exchange; block 0, the largest, first), each block's per-lane sums
+// go to the owner's LDS, and the owner adds them in block order -- the order a single wavefront
+// uses, so the result does not depend on who computed what. Helpers keep the packed C of the
+// individual they last worked for in registers. All control flow is wave-uniform and in straight
+// `if`s over compile-time block numbers (a run-time block number dispatched by a switch inside the
+// claim loop compiled into code that never left the loop). Every wait is bounded and raises the
+// workgroup's abort word, which turns the evaluation into a NaN (status 5 for that individual).
 constexpr int RES_WAVES = 4;
+constexpr int RC_NIDLE = 0, RC_ABORT = 1, RC_OWNER = 8, RC_STRIDE = 12;
+constexpr int RO_CLAIM = 0 /* .. 3 */, RO_DONE = 4, RO_AREADY = 5, RO_EPOCH = 6, RO_I = 7, RO_N = 8,
+              RO_LEFT = 9;
+constexpr int RC_WORDS = RC_OWNER + RC_STRIDE * RES_WAVES;
+constexpr unsigned long long RES_HELPER_LIMIT = 300000000ull;  // 3 s of the 100 MHz clock
+
+template <int NMAX>
+constexpr int resident_solo_doubles() {
+  return NMAX * NMAX + 16 + 3 * 64 + (int)((sizeof(lbcore::State<3, 5>) + 127) / 128) * 16;
+}
+template <int NMAX>
+constexpr int resident_part_doubles() {  // [block][s1, s2, s3, cor][lane]
+  return ((NMAX + 15) / 16) * 4 * 64;
+}
+// Helpers need 2 KB of LDS per column block and wavefront: there is room for that up to 56 rows.
+template <int NMAX>
+constexpr bool resident_help() {
+  return (size_t)RES_WAVES * (resident_solo_doubles<NMAX>() + resident_part_doubles<NMAX>()) *
+                 sizeof(double) + 2048 <= 160 * 1024;
+}
 template <int NMAX>
 constexpr int resident_wave_doubles() {
-  return NMAX * NMAX + 16 + 3 * 64 + (int)((sizeof(lbcore::State<3, 5>) + 127) / 128) * 16;
+  return resident_solo_doubles<NMAX>() + (resident_help<NMAX>() ? resident_part_doubles<NMAX>() : 0);
+}
+
+// Control words in LDS: one lane writes, every lane gets the same (scalar) value back.
+__device__ __forceinline__ int ctl_load(const int* p) {
+  return __builtin_amdgcn_readfirstlane(
+      __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void ctl_store(int* p, int v, int lane) {
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ctl_add(int* p, int v, int lane) {
+  if (lane == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool ctl_claim(int* p, int lane) {  // true: the word was 0 and is ours
+  int v = 1;
+  if (lane == 0) v = __hip_atomic_exchange(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(v) == 0;
+}
+
+// Diagnostics of a workgroup that gave up on a wait (first writer wins): [0] code (1 owner waiting
+// for block sums, 2 helper waiting for alpha, 3 helper loop beyond the time limit), [1] workgroup,
+// [2] wavefront, [3] idle count, then done / alpha-ready / epoch / blocks left of the four boards.
+static __device__ unsigned long long g_res_diag[24];
+__device__ __noinline__ void resident_diag(int code, int wave, const int* s_ctl) {
+  if ((threadIdx.x & 63) != 0) return;
+  if (atomicCAS(&g_res_diag[0], 0ull, (unsigned long long)code) != 0ull) return;
+  g_res_diag[1] = blockIdx.x;
+  g_res_diag[2] = wave;
+  g_res_diag[3] = __hip_atomic_load(s_ctl + RC_NIDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int words[4] = {RO_DONE, RO_AREADY, RO_EPOCH, RO_LEFT};
+  for (int o = 0; o < RES_WAVES; ++o)
+    for (int q = 0; q < 4; ++q)
+      g_res_diag[4 + 4 * o + q] = (unsigned long long)(unsigned)__hip_atomic_load(
+          s_ctl + RC_OWNER + RC_STRIDE * o + words[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The rest of an evaluation whose column blocks are on the board (see indiv_mstep_kernel). Out
+// of line, with its LDS pointers typed as such: inlined next to the code of an evaluation that
+// runs alone, it cost that one 2-3 % (spills and waits at the joins of the two).
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) int lds_int;
+struct HelpedSums {
+  double s1, s2, s3, cor, ssq;
+  int ok;
+};
+template <int NMAX>
+__device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
+    lds_double* Ks_, lds_int* s_ctl_, lds_double* s_par_, int wave, int lane, int n, int i, int epoch,
+    SEParams p, double zr, const double* __restrict__ cpack, bool with_c) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  double* Ks = (double*)Ks_;
+  int* s_ctl = (int*)s_ctl_;
+  double* s_parw = (double*)s_par_ + 4 * wave;
+  double* tbuf = Ks + NMAX * NMAX + 16;
+  double* zbuf = tbuf + 64;
+  double* abuf = zbuf + 64;
+  double* part = Ks + resident_solo_doubles<NMAX>();
+  int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
+  int* abort_ = s_ctl + RC_ABORT;
+  HelpedSums r;
+  if (lane == 0) {
+    s_parw[0] = p.th1;
+    s_parw[1] = p.h;
+    s_parw[2] = p.sig2;
+    s_parw[3] = p.eth1;
+  }
+  ctl_store(ctl + RO_I, i, lane);
+  ctl_store(ctl + RO_N, n, lane);
+  ctl_store(ctl + RO_EPOCH, epoch, lane);
+  ctl_store(ctl + RO_DONE, 0, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // K^-1 and the board first
+  ctl_store(ctl + RO_LEFT, NT, lane);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) ctl_store(ctl + RO_CLAIM + jt, 0, lane);
+
+  __builtin_amdgcn_sched_barrier(0);
+  double cf[NK][NT];
+  if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
+  r.ssq = wave_sum(zr * alpha);
+  abuf[lane] = alpha;
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  ctl_store(ctl + RO_AREADY, epoch, lane);
+
+  for_blocks<NMAX>([&](auto JT) {
+    constexpr int jt = decltype(JT)::value;
+    if (ctl_claim(ctl + RO_CLAIM + jt, lane)) {
+      double q1, q2, q3, qc;
+      eval_block<NMAX, jt>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
+      double* pj = part + jt * 256 + lane;
+      pj[0] = q1;
+      pj[64] = q2;
+      pj[128] = q3;
+      pj[192] = qc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      ctl_add(ctl + RO_LEFT, -1, lane);
+      ctl_add(ctl + RO_DONE, 1, lane);
+    }
+  });
+  const bool ok = lds_wait_ge(ctl + RO_DONE, NT, abort_);
+  if (!ok) resident_diag(1, wave, s_ctl);
+  r.s1 = r.s2 = r.s3 = r.cor = 0.0;
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const double* pj = part + jt * 256 + lane;
+    r.s1 += pj[0];
+    r.s2 += pj[64];
+    r.s3 += pj[128];
+    r.cor += pj[192];
+  }
+  r.ok = ok ? 1 : 0;
+  wave_sync();
+  return r;
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(224))) void indiv_mstep_kernel(
+__global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(256))) void indiv_mstep_kernel(
     int M, const int* __restrict__ order, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ mean, const double* __restrict__ cpack, int mode,
     const double* __restrict__ theta0, int lm,
     double factr, double pgtol, int maxit, double* __restrict__ theta_out,
     double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
-    int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket) {
+    int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket,
+    int help_on) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  constexpr bool HELP = resident_help<NMAX>();
+  static_assert(NT <= 4, "four claim words per board");
   extern __shared__ __attribute__((aligned(16))) double dyn[];
+  __shared__ int s_ctl[RC_WORDS];
+  __shared__ double s_par[RES_WAVES][4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS bases in SGPRs
   // this wavefront's LDS: Ks (NMAX^2 + 16; fragment reads of the last rows run up to 12 doubles
-  // past the end, into masked results), timestamps, residuals, alpha, optimiser state
+  // past the end, into masked results), timestamps, residuals, alpha, optimiser state, block sums
   double* Ks = dyn + (size_t)wave * resident_wave_doubles<NMAX>();
   double* tbuf = Ks + NMAX * NMAX + 16;
   double* zbuf = tbuf + 64;
   double* abuf = zbuf + 64;
   lbcore::State<3, 5>* st = reinterpret_cast<lbcore::State<3, 5>*>(abuf + 64);
-  int i = 0, n = 0;
+  double* part = Ks + resident_solo_doubles<NMAX>();
+  int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
+  int* abort_ = s_ctl + RC_ABORT;
+  if (threadIdx.x < RC_WORDS) {  // boards closed (every block claimed), everything else zero
+    const int q = ((int)threadIdx.x - RC_OWNER) % RC_STRIDE;
+    s_ctl[threadIdx.x] = ((int)threadIdx.x >= RC_OWNER && q >= RO_CLAIM && q < RO_CLAIM + 4) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool with_c = (mode == 0 && cpack != nullptr);
+  int i = 0, n = 0, epoch = 0;
   bool fresh = true;
   double fx0 = 0.0;
 #pragma unroll 1
@@ -1027,10 +1254,53 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const double th1 = st->xtrial[0], th2 = st->xtrial[1], sigma = st->xtrial[2];
-    double f, g[3] = {0.0, 0.0, 0.0};
+    const SEParams p = se_params(th1, th2, sigma);
+    const double zr = zbuf[lane];
+    double logdet;
     int info;
-    indiv_eval_body<NMAX>(lane, n, i, th1, th2, sigma, tbuf, zbuf, abuf, Ks, cpack, mode, 1, f,
-                          g, info);
+    eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
+
+    // Somebody idle in this workgroup? Then the column blocks go on the board. (Two copies of the
+    // rest of the evaluation, chosen here: sharing the code between the two cases costs the one
+    // that runs alone 3 % -- spills and waits at the joins.)
+    bool helped = false;
+    if constexpr (HELP) helped = help_on != 0 && ctl_load(s_ctl + RC_NIDLE) > 0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0, ssq;
+    if (!helped) {
+      __builtin_amdgcn_sched_barrier(0);
+      double cf[NK][NT];
+      if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
+      ssq = wave_sum(zr * alpha);
+      abuf[lane] = alpha;
+      wave_sync();  // abuf visible
+      for_blocks<NMAX>([&](auto JT) {
+        double q1, q2, q3, qc;
+        eval_block<NMAX, decltype(JT)::value>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
+        s1 += q1;
+        s2 += q2;
+        s3 += q3;
+        cor += qc;
+      });
+    }
+    if constexpr (HELP) {
+      if (helped) {
+        ++epoch;
+        const HelpedSums r = resident_helped_tail<NMAX>(
+            (lds_double*)Ks, (lds_int*)s_ctl, (lds_double*)&s_par[0][0], wave, lane, n, i, epoch, p, zr,
+            cpack, with_c);
+        s1 = r.s1;
+        s2 = r.s2;
+        s3 = r.s3;
+        cor = r.cor;
+        ssq = r.ssq;
+        if (!r.ok) info = -999;
+      }
+    }
+    double f, g[3] = {0.0, 0.0, 0.0};
+    eval_finish(n, sigma, logdet, ssq, info, with_c, s1, s2, s3, cor, f, g);
+
     fx0 = (st->nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
     wave_sync();  // the body's LDS traffic is over before the state is stepped
     lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
@@ -1047,6 +1317,82 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
         status_out[i] = st->status;
       }
       fresh = true;
+    }
+  }
+
+  // ---- no tickets left: help the wavefronts of this workgroup that still run a problem
+  if constexpr (HELP) {
+    if (help_on == 0) return;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    ctl_add(s_ctl + RC_NIDLE, 1, lane);
+    int tag = -1;  // individual whose packed C is in cf
+    const unsigned long long t_idle = wall_clock64();  // 100 MHz
+    double cf[NK][NT];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) cf[kk][it] = 0.0;
+#pragma unroll 1
+    for (;;) {
+      if (ctl_load(abort_) != 0) break;
+      if (ctl_load(s_ctl + RC_NIDLE) >= RES_WAVES) break;
+      bool did = false;
+#pragma unroll 1
+      for (int q = 1; q < RES_WAVES; ++q) {
+        const int o = (wave + q) & (RES_WAVES - 1);
+        int* co = s_ctl + RC_OWNER + RC_STRIDE * o;
+        if (ctl_load(co + RO_LEFT) <= 0) continue;
+        const double* oKs = dyn + (size_t)o * resident_wave_doubles<NMAX>();
+        const double* otbuf = oKs + NMAX * NMAX + 16;
+        const double* oabuf = otbuf + 128;
+        double* opart = const_cast<double*>(oKs) + resident_solo_doubles<NMAX>();
+        for_blocks<NMAX>([&](auto JT) {
+          constexpr int jt = decltype(JT)::value;
+          if (ctl_claim(co + RO_CLAIM + jt, lane)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const int oi = ctl_load(co + RO_I);
+            const int on = ctl_load(co + RO_N);
+            const int oe = ctl_load(co + RO_EPOCH);
+            SEParams p;
+            p.th1 = s_par[o][0];
+            p.h = s_par[o][1];
+            p.sig2 = s_par[o][2];
+            p.eth1 = s_par[o][3];
+            if (with_c && tag != oi) {
+              __builtin_amdgcn_sched_barrier(0);
+              eval_load_c<NMAX>(cf, cpack, oi, lane);
+              __builtin_amdgcn_sched_barrier(0);
+              tag = oi;
+            }
+            double q1, q2, q3, qc;
+            eval_block<NMAX, jt>(
+                lane, on, p, with_c, cf, oKs, otbuf, oabuf,
+                [&] {
+                  if (!lds_wait_ge(co + RO_AREADY, oe, abort_)) resident_diag(2, wave, s_ctl);
+                },
+                q1, q2, q3, qc);
+            double* pj = opart + jt * 256 + lane;
+            pj[0] = q1;
+            pj[64] = q2;
+            pj[128] = q3;
+            pj[192] = qc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            ctl_add(co + RO_LEFT, -1, lane);
+            ctl_add(co + RO_DONE, 1, lane);
+            did = true;
+          }
+        });
+      }
+      if (!did) {
+        // (nothing in this launch lasts seconds: a helper that has waited that long gives up)
+        if (wall_clock64() - t_idle > RES_HELPER_LIMIT) {
+          resident_diag(3, wave, s_ctl);
+          ctl_store(abort_, 1, lane);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
     }
   }
 }
@@ -1371,6 +1717,13 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
 // Cap on the workgroups (= compute units) of the device-resident M-step; 0 = every compute unit.
 static std::atomic<int> g_resident_max_wgs{0};
 void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
+// Idle wavefronts help the running ones of their workgroup (default on; same results either way).
+static std::atomic<int> g_resident_help{1};
+void set_resident_help(int v) { g_resident_help.store(v & 3); }  // bit 1: every compute unit even for few individuals (diagnostic)
+int resident_diag_read(unsigned long long* h24) {
+  return check_hip(hipMemcpyFromSymbol(h24, HIP_SYMBOL(g_res_diag), 24 * sizeof(unsigned long long)),
+                   "resident diagnostics");
+}
 
 // Ticket counters of the resident launches: a small ring in device memory, one word per launch
 // (zeroed on the launch's stream), so that launches running at the same time on one GPU -- several
@@ -1432,11 +1785,11 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
   const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
   const int cus = device_compute_units();
   int grid = (M + RES_WAVES - 1) / RES_WAVES;
-  if (grid > cus) grid = cus;  // persistent: one workgroup fills a compute unit
+  if (grid > cus || (g_resident_help.load(std::memory_order_relaxed) & 2)) grid = cus;  // persistent: one workgroup fills a compute unit
   if (cap > 0 && grid > cap) grid = cap;
   hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RES_WAVES), dyn, st, M, order, off,
                      t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out,
-                     fx0_out, iters, nfev, status, ticket);
+                     fx0_out, iters, nfev, status, ticket, g_resident_help.load(std::memory_order_relaxed) & 1);
   return check_hip(hipGetLastError(), "indiv_mstep");
 }
 

@@ -358,6 +358,37 @@ def test_resident_mstep_equals_lock_step_mstep(gpu):
     assert np.abs(a["f"] - b["f"]).max() <= 1e-12 * np.abs(b["f"]).max()
 
 
+@pytest.mark.parametrize("sizes", [[5, 30, 17, 50, 42, 30, 8, 48, 1, 2], [50] * 37, [40], [33, 12]],
+                         ids=["ragged", "37x50", "one", "two"])
+def test_resident_mstep_helper_wavefronts_do_not_change_results(gpu, sizes):
+    """Idle wavefronts of a workgroup take column blocks of the evaluations still running next to
+    them (magma_set_option("resident_help", ...): 0 off, 1 on, 3 on with every compute unit
+    launched, so that most workgroups consist of helpers only). Block sums are added in block
+    order whoever computed them: every mode gives the bits of the lock-step loop, and no workgroup
+    gave up on a wait (magma_debug_resident_diag word 0)."""
+    from magma_amd.engine import Dataset, Engine
+    _lib = gpu["_lib"]
+    rng = np.random.default_rng(31)
+    db = _ragged_db(rng, sizes)
+    ids = orc.unique_in_order(db["ID"])
+    hp = _random_hp(rng, ids)
+    thi = np.array([hp["theta_i"][i] for i in ids])
+    eng = Engine(Dataset(db))
+    eng.e_step(hp["theta_0"], thi, float(np.mean(thi[:, 2])), 0.3)
+    ref = eng.be.indiv_mstep(thi)
+    try:
+        for mode in (0, 1, 3, 3):
+            _lib.call("magma_set_option", b"resident_help", C.c_long(mode))
+            a = eng.be.indiv_mstep_resident(thi)
+            for k in ("status", "nfev", "iters", "x", "f", "f_x0"):
+                assert np.array_equal(a[k], ref[k], equal_nan=True), (mode, k)
+    finally:
+        _lib.call("magma_set_option", b"resident_help", C.c_long(1))
+    diag = (C.c_ulonglong * 24)()
+    _lib.call("magma_debug_resident_diag", diag)
+    assert diag[0] == 0, list(diag)
+
+
 def test_results_do_not_depend_on_stale_lds(gpu):
     """LDS is not cleared between workgroups. Every kernel's padding tricks (identity padding,
     fragment reads that run past a row, zero-padded operands) must select stale words away, never
