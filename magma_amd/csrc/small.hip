@@ -1029,7 +1029,9 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
                                                              double factr, double pgtol,
                                                              int maxit) {
   const double g[3] = {g0, g1, g2};
-  lbcore::tell(*st, f, g, factr, pgtol, maxit);
+  // (three variables here; five correction pairs is optim()'s default lmm)
+  if (st->m == 5) lbcore::tell_fixed<3, 5>(*st, f, g, factr, pgtol, maxit);
+  else lbcore::tell_fixed<3, 0>(*st, f, g, factr, pgtol, maxit);
 }
 
 // Workgroups of four wavefronts, each wavefront an independent worker with its own slice of the
@@ -1116,6 +1118,14 @@ __device__ __noinline__ void resident_diag(int code, int wave, const int* s_ctl)
 // The rest of an evaluation whose column blocks are on the board (see indiv_mstep_kernel). Out
 // of line, with its LDS pointers typed as such: inlined next to the code of an evaluation that
 // runs alone, it cost that one 2-3 % (spills and waits at the joins of the two).
+#ifdef MAGMA_RES_STAMPS
+__device__ unsigned long long g_res_stamps[16];
+#define RSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_res_stamps[k], t_ - rs_prev); rs_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RSTAMP_INIT() unsigned long long rs_prev = __builtin_readcyclecounter()
+#else
+#define RSTAMP(k)
+#define RSTAMP_INIT()
+#endif
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) int lds_int;
 struct HelpedSums {
@@ -1137,6 +1147,7 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
   int* abort_ = s_ctl + RC_ABORT;
   HelpedSums r;
+  RSTAMP_INIT();
   if (lane == 0) {
     s_parw[0] = p.th1;
     s_parw[1] = p.h;
@@ -1151,6 +1162,7 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   ctl_store(ctl + RO_LEFT, NT, lane);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) ctl_store(ctl + RO_CLAIM + jt, 0, lane);
+  RSTAMP(0);
 
   __builtin_amdgcn_sched_barrier(0);
   double cf[NK][NT];
@@ -1162,6 +1174,7 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   wave_sync();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   ctl_store(ctl + RO_AREADY, epoch, lane);
+  RSTAMP(1);
 
   for_blocks<NMAX>([&](auto JT) {
     constexpr int jt = decltype(JT)::value;
@@ -1178,7 +1191,9 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
       ctl_add(ctl + RO_DONE, 1, lane);
     }
   });
+  RSTAMP(2);
   const bool ok = lds_wait_ge(ctl + RO_DONE, NT, abort_);
+  RSTAMP(3);
   if (!ok) resident_diag(1, wave, s_ctl);
   r.s1 = r.s2 = r.s3 = r.cor = 0.0;
 #pragma unroll
@@ -1191,6 +1206,10 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   }
   r.ok = ok ? 1 : 0;
   wave_sync();
+  RSTAMP(4);
+#ifdef MAGMA_RES_STAMPS
+  if (lane == 0) atomicAdd(&g_res_stamps[15], 1ull);
+#endif
   return r;
 }
 
@@ -1258,7 +1277,13 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     const double zr = zbuf[lane];
     double logdet;
     int info;
+#ifdef MAGMA_RES_STAMPS
+    const unsigned long long rs_e0 = __builtin_readcyclecounter();
+#endif
     eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
+#ifdef MAGMA_RES_STAMPS
+    const unsigned long long rs_e1 = __builtin_readcyclecounter();
+#endif
 
     // Somebody idle in this workgroup? Then the column blocks go on the board. (Two copies of the
     // rest of the evaluation, chosen here: sharing the code between the two cases costs the one
@@ -1287,6 +1312,10 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     if constexpr (HELP) {
       if (helped) {
         ++epoch;
+#ifdef MAGMA_RES_STAMPS
+        const unsigned long long rs_c0 = __builtin_readcyclecounter();
+        if (lane == 0) atomicAdd(&g_res_stamps[10], rs_c0 - rs_e1);  // factor end -> call
+#endif
         const HelpedSums r = resident_helped_tail<NMAX>(
             (lds_double*)Ks, (lds_int*)s_ctl, (lds_double*)&s_par[0][0], wave, lane, n, i, epoch, p, zr,
             cpack, with_c);
@@ -1296,6 +1325,9 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
         cor = r.cor;
         ssq = r.ssq;
         if (!r.ok) info = -999;
+#ifdef MAGMA_RES_STAMPS
+        if (lane == 0) atomicAdd(&g_res_stamps[11], __builtin_readcyclecounter() - rs_c0);  // call
+#endif
       }
     }
     double f, g[3] = {0.0, 0.0, 0.0};
@@ -1303,8 +1335,22 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
 
     fx0 = (st->nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
     wave_sync();  // the body's LDS traffic is over before the state is stepped
+#ifdef MAGMA_RES_STAMPS
+    const unsigned long long rs_t0 = __builtin_readcyclecounter();
+#endif
     lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
+#ifdef MAGMA_RES_STAMPS
+    if (helped && lane == 0) atomicAdd(&g_res_stamps[12], __builtin_readcyclecounter() - rs_t0);  // tell
+    if (helped && lane == 0) atomicAdd(&g_res_stamps[13], rs_t0 - rs_e1);  // factor end -> tell
+#endif
     wave_sync();
+#ifdef MAGMA_RES_STAMPS
+    if (helped && lane == 0) {
+      const unsigned long long rs_e2 = __builtin_readcyclecounter();
+      atomicAdd(&g_res_stamps[8], rs_e1 - rs_e0);   // factor
+      atomicAdd(&g_res_stamps[9], rs_e2 - rs_e0);   // whole evaluation + optimiser step
+    }
+#endif
     if (st->status != 0) {
       if ((threadIdx.x & 63) == 0) {
         const double nanv = __longlong_as_double(0x7ff8000000000000LL);
@@ -1721,8 +1767,13 @@ void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v
 static std::atomic<int> g_resident_help{1};
 void set_resident_help(int v) { g_resident_help.store(v & 3); }  // bit 1: every compute unit even for few individuals (diagnostic)
 int resident_diag_read(unsigned long long* h24) {
+#ifdef MAGMA_RES_STAMPS
+  return check_hip(hipMemcpyFromSymbol(h24, HIP_SYMBOL(g_res_stamps), 16 * sizeof(unsigned long long)),
+                   "resident stamps");
+#else
   return check_hip(hipMemcpyFromSymbol(h24, HIP_SYMBOL(g_res_diag), 24 * sizeof(unsigned long long)),
                    "resident diagnostics");
+#endif
 }
 
 // Ticket counters of the resident launches: a small ring in device memory, one word per launch
