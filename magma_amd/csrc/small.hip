@@ -662,7 +662,9 @@ __global__ __launch_bounds__(256) void update_inv_kernel(
 // strings them together for one wavefront.
 //
 // Stages 1-3: K(theta) (+ C in mode 1) -> K^-1 in Ks (LDS), log|K|, info. Ends with a wave_sync().
-template <int NMAX>
+// FROM_LDS: K (unscaled, zero beyond n) was put into Ks by eval_build_row, by this wavefront or by
+// others; stage 1 then only loads it.
+template <int NMAX, bool FROM_LDS = false>
 __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEParams& p,
                                             const double* tbuf, double* Ks,
                                             const double* __restrict__ cpack, int mode,
@@ -678,28 +680,44 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
 
   // ---- 1. K in accumulator layout (rows >= NMAX are never touched: compile-time skip)
   v4d A[NT][NT];
-  double tcol[NT];
+  if constexpr (FROM_LDS) {
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+    for (int it = 0; it < NT; ++it)
 #pragma unroll
-  for (int it = 0; it < NT; ++it) {
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * it + 4 * v + g;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (16 * it + 4 * v >= NMAX) {
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
-        continue;
+        for (int jt = 0; jt < NT; ++jt) {
+          const int c = 16 * jt + l;
+          if (16 * it + 4 * v >= NMAX) A[it][jt][v] = 0.0;
+          else A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
+        }
       }
-      const int r = 16 * it + 4 * v + g;
-      const double trow = tbuf[r];
+    wave_sync();  // every load is issued before the sweep reuses the head of Ks
+  } else {
+    double tcol[NT];
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const int c = 16 * jt + l;
-        const double d = trow - tcol[jt];
-        double kv = exp(p.th1 - p.h * d * d);
-        kv = (r == c) ? (p.eth1 + p.sig2) : kv;
-        A[it][jt][v] = (r < n && c < n) ? kv : 0.0;
-        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
+    for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (16 * it + 4 * v >= NMAX) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
+          continue;
+        }
+        const int r = 16 * it + 4 * v + g;
+        const double trow = tbuf[r];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          const int c = 16 * jt + l;
+          const double d = trow - tcol[jt];
+          double kv = exp(p.th1 - p.h * d * d);
+          kv = (r == c) ? (p.eth1 + p.sig2) : kv;
+          A[it][jt][v] = (r < n && c < n) ? kv : 0.0;
+          __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
+        }
       }
     }
   }
@@ -765,6 +783,32 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
       }
     }
   wave_sync();
+}
+
+// Tile row IT of K (mode 0: no C), unscaled, as eval_factor's stage 1 computes it, into Ks.
+template <int NMAX, int IT>
+__device__ __forceinline__ void eval_build_row(int lane, int n, const SEParams& p,
+                                               const double* tbuf, double* Ks) {
+  constexpr int NT = (NMAX + 15) / 16, LD = NMAX;
+  const int l = lane & 15, g = lane >> 4;
+  double tcol[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    if (16 * IT + 4 * v >= NMAX) continue;
+    const int r = 16 * IT + 4 * v + g;
+    const double trow = tbuf[r];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int c = 16 * jt + l;
+      const double d = trow - tcol[jt];
+      double kv = exp(p.th1 - p.h * d * d);
+      kv = (r == c) ? (p.eth1 + p.sig2) : kv;
+      if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = (r < n && c < n) ? kv : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 }
 
 // The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52). (Left alone the compiler
@@ -1056,9 +1100,9 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
 // claim loop compiled into code that never left the loop). Every wait is bounded and raises the
 // workgroup's abort word, which turns the evaluation into a NaN (status 5 for that individual).
 constexpr int RES_WAVES = 4;
-constexpr int RC_NIDLE = 0, RC_ABORT = 1, RC_OWNER = 8, RC_STRIDE = 12;
+constexpr int RC_NIDLE = 0, RC_ABORT = 1, RC_OWNER = 8, RC_STRIDE = 16;
 constexpr int RO_CLAIM = 0 /* .. 3 */, RO_DONE = 4, RO_AREADY = 5, RO_EPOCH = 6, RO_I = 7, RO_N = 8,
-              RO_LEFT = 9;
+              RO_LEFT = 9, RO_BCLAIM = 10 /* .. 13 */, RO_BDONE = 14, RO_BLEFT = 15;
 constexpr int RC_WORDS = RC_OWNER + RC_STRIDE * RES_WAVES;
 constexpr unsigned long long RES_HELPER_LIMIT = 300000000ull;  // 3 s of the 100 MHz clock
 
@@ -1100,7 +1144,8 @@ __device__ __forceinline__ bool ctl_claim(int* p, int lane) {  // true: the word
 
 // Diagnostics of a workgroup that gave up on a wait (first writer wins): [0] code (1 owner waiting
 // for block sums, 2 helper waiting for alpha, 3 helper loop beyond the time limit), [1] workgroup,
-// [2] wavefront, [3] idle count, then done / alpha-ready / epoch / blocks left of the four boards.
+// [2] wavefront, [3] idle count, then done / alpha-ready / epoch / blocks left of the four boards
+// (code 4: owner waiting for the tile rows of K).
 static __device__ unsigned long long g_res_diag[24];
 __device__ __noinline__ void resident_diag(int code, int wave, const int* s_ctl) {
   if ((threadIdx.x & 63) != 0) return;
@@ -1129,13 +1174,13 @@ __device__ unsigned long long g_res_stamps[16];
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) int lds_int;
 struct HelpedSums {
-  double s1, s2, s3, cor, ssq;
-  int ok;
+  double s1, s2, s3, cor, ssq, logdet;
+  int info, ok;
 };
 template <int NMAX>
-__device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
+__device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
     lds_double* Ks_, lds_int* s_ctl_, lds_double* s_par_, int wave, int lane, int n, int i, int epoch,
-    SEParams p, double zr, const double* __restrict__ cpack, bool with_c) {
+    SEParams p, double zr, const double* __restrict__ cpack) {
   constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
   double* Ks = (double*)Ks_;
   int* s_ctl = (int*)s_ctl_;
@@ -1146,8 +1191,10 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   double* part = Ks + resident_solo_doubles<NMAX>();
   int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
   int* abort_ = s_ctl + RC_ABORT;
+  const bool with_c = (cpack != nullptr);
   HelpedSums r;
   RSTAMP_INIT();
+  // ---- the board, then K by tile rows (whoever claims them), K^-1 by this wavefront
   if (lane == 0) {
     s_parw[0] = p.th1;
     s_parw[1] = p.h;
@@ -1158,7 +1205,28 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
   ctl_store(ctl + RO_N, n, lane);
   ctl_store(ctl + RO_EPOCH, epoch, lane);
   ctl_store(ctl + RO_DONE, 0, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // K^-1 and the board first
+  ctl_store(ctl + RO_BDONE, 0, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  ctl_store(ctl + RO_BLEFT, NT, lane);
+#pragma unroll
+  for (int it = 0; it < NT; ++it) ctl_store(ctl + RO_BCLAIM + it, 0, lane);
+  for_blocks<NMAX>([&](auto IT) {
+    constexpr int it = decltype(IT)::value;
+    if (ctl_claim(ctl + RO_BCLAIM + it, lane)) {
+      eval_build_row<NMAX, it>(lane, n, p, tbuf, Ks);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      ctl_add(ctl + RO_BLEFT, -1, lane);
+      ctl_add(ctl + RO_BDONE, 1, lane);
+    }
+  });
+  bool ok = lds_wait_ge(ctl + RO_BDONE, NT, abort_);
+  if (!ok) resident_diag(4, wave, s_ctl);
+  RSTAMP(5);
+  eval_factor<NMAX, true>(lane, n, i, p, tbuf, Ks, nullptr, 0, r.logdet, r.info);
+  RSTAMP(6);
+
+  // ---- the column blocks of stages 4 / 5
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // K^-1 first
   ctl_store(ctl + RO_LEFT, NT, lane);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) ctl_store(ctl + RO_CLAIM + jt, 0, lane);
@@ -1192,9 +1260,11 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_tail(
     }
   });
   RSTAMP(2);
-  const bool ok = lds_wait_ge(ctl + RO_DONE, NT, abort_);
+  if (!lds_wait_ge(ctl + RO_DONE, NT, abort_)) {
+    resident_diag(1, wave, s_ctl);
+    ok = false;
+  }
   RSTAMP(3);
-  if (!ok) resident_diag(1, wave, s_ctl);
   r.s1 = r.s2 = r.s3 = r.cor = 0.0;
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
@@ -1242,7 +1312,8 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
   int* abort_ = s_ctl + RC_ABORT;
   if (threadIdx.x < RC_WORDS) {  // boards closed (every block claimed), everything else zero
     const int q = ((int)threadIdx.x - RC_OWNER) % RC_STRIDE;
-    s_ctl[threadIdx.x] = ((int)threadIdx.x >= RC_OWNER && q >= RO_CLAIM && q < RO_CLAIM + 4) ? 1 : 0;
+    const bool claim = (q >= RO_CLAIM && q < RO_CLAIM + 4) || (q >= RO_BCLAIM && q < RO_BCLAIM + 4);
+    s_ctl[threadIdx.x] = ((int)threadIdx.x >= RC_OWNER && claim) ? 1 : 0;
   }
   __syncthreads();
   const bool with_c = (mode == 0 && cpack != nullptr);
@@ -1277,21 +1348,17 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     const double zr = zbuf[lane];
     double logdet;
     int info;
+    // Somebody idle in this workgroup? Then this evaluation goes on the board (mode 0 only: K
+    // without C). Its code is a function of its own: sharing the code between the two cases costs
+    // the one that runs alone 3 % -- spills and waits at the joins.
+    bool helped = false;
+    if constexpr (HELP) helped = help_on != 0 && mode == 0 && ctl_load(s_ctl + RC_NIDLE) > 0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0, ssq;
 #ifdef MAGMA_RES_STAMPS
     const unsigned long long rs_e0 = __builtin_readcyclecounter();
 #endif
-    eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
-#ifdef MAGMA_RES_STAMPS
-    const unsigned long long rs_e1 = __builtin_readcyclecounter();
-#endif
-
-    // Somebody idle in this workgroup? Then the column blocks go on the board. (Two copies of the
-    // rest of the evaluation, chosen here: sharing the code between the two cases costs the one
-    // that runs alone 3 % -- spills and waits at the joins.)
-    bool helped = false;
-    if constexpr (HELP) helped = help_on != 0 && ctl_load(s_ctl + RC_NIDLE) > 0;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0, ssq;
     if (!helped) {
+      eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
       __builtin_amdgcn_sched_barrier(0);
       double cf[NK][NT];
       if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
@@ -1312,22 +1379,16 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     if constexpr (HELP) {
       if (helped) {
         ++epoch;
-#ifdef MAGMA_RES_STAMPS
-        const unsigned long long rs_c0 = __builtin_readcyclecounter();
-        if (lane == 0) atomicAdd(&g_res_stamps[10], rs_c0 - rs_e1);  // factor end -> call
-#endif
-        const HelpedSums r = resident_helped_tail<NMAX>(
-            (lds_double*)Ks, (lds_int*)s_ctl, (lds_double*)&s_par[0][0], wave, lane, n, i, epoch, p, zr,
-            cpack, with_c);
+        const HelpedSums r = resident_helped_eval<NMAX>((lds_double*)Ks, (lds_int*)s_ctl,
+                                                        (lds_double*)&s_par[0][0], wave, lane, n, i,
+                                                        epoch, p, zr, cpack);
         s1 = r.s1;
         s2 = r.s2;
         s3 = r.s3;
         cor = r.cor;
         ssq = r.ssq;
-        if (!r.ok) info = -999;
-#ifdef MAGMA_RES_STAMPS
-        if (lane == 0) atomicAdd(&g_res_stamps[11], __builtin_readcyclecounter() - rs_c0);  // call
-#endif
+        logdet = r.logdet;
+        info = r.ok ? r.info : -999;
       }
     }
     double f, g[3] = {0.0, 0.0, 0.0};
@@ -1341,13 +1402,12 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
 #ifdef MAGMA_RES_STAMPS
     if (helped && lane == 0) atomicAdd(&g_res_stamps[12], __builtin_readcyclecounter() - rs_t0);  // tell
-    if (helped && lane == 0) atomicAdd(&g_res_stamps[13], rs_t0 - rs_e1);  // factor end -> tell
+    if (helped && lane == 0) atomicAdd(&g_res_stamps[13], rs_t0 - rs_e0);  // start -> tell
 #endif
     wave_sync();
 #ifdef MAGMA_RES_STAMPS
     if (helped && lane == 0) {
       const unsigned long long rs_e2 = __builtin_readcyclecounter();
-      atomicAdd(&g_res_stamps[8], rs_e1 - rs_e0);   // factor
       atomicAdd(&g_res_stamps[9], rs_e2 - rs_e0);   // whole evaluation + optimiser step
     }
 #endif
@@ -1388,11 +1448,30 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
       for (int q = 1; q < RES_WAVES; ++q) {
         const int o = (wave + q) & (RES_WAVES - 1);
         int* co = s_ctl + RC_OWNER + RC_STRIDE * o;
-        if (ctl_load(co + RO_LEFT) <= 0) continue;
-        const double* oKs = dyn + (size_t)o * resident_wave_doubles<NMAX>();
+        double* oKs = dyn + (size_t)o * resident_wave_doubles<NMAX>();
         const double* otbuf = oKs + NMAX * NMAX + 16;
         const double* oabuf = otbuf + 128;
-        double* opart = const_cast<double*>(oKs) + resident_solo_doubles<NMAX>();
+        double* opart = oKs + resident_solo_doubles<NMAX>();
+        if (ctl_load(co + RO_BLEFT) > 0) {  // tile rows of K
+          for_blocks<NMAX>([&](auto IT) {
+            constexpr int it = decltype(IT)::value;
+            if (ctl_claim(co + RO_BCLAIM + it, lane)) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+              const int on = ctl_load(co + RO_N);
+              SEParams p;
+              p.th1 = s_par[o][0];
+              p.h = s_par[o][1];
+              p.sig2 = s_par[o][2];
+              p.eth1 = s_par[o][3];
+              eval_build_row<NMAX, it>(lane, on, p, otbuf, oKs);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+              ctl_add(co + RO_BLEFT, -1, lane);
+              ctl_add(co + RO_BDONE, 1, lane);
+              did = true;
+            }
+          });
+        }
+        if (ctl_load(co + RO_LEFT) <= 0) continue;
         for_blocks<NMAX>([&](auto JT) {
           constexpr int jt = decltype(JT)::value;
           if (ctl_claim(co + RO_CLAIM + jt, lane)) {
