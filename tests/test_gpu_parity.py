@@ -358,8 +358,9 @@ def test_resident_mstep_equals_lock_step_mstep(gpu):
     assert np.abs(a["f"] - b["f"]).max() <= 1e-12 * np.abs(b["f"]).max()
 
 
-@pytest.mark.parametrize("sizes", [[5, 30, 17, 50, 42, 30, 8, 48, 1, 2], [50] * 37, [40], [33, 12]],
-                         ids=["ragged", "37x50", "one", "two"])
+@pytest.mark.parametrize("sizes", [[5, 30, 17, 50, 42, 30, 8, 48, 1, 2], [50] * 37, [40], [33, 12],
+                                   [12, 9, 16], [20] * 5, [56, 3]],
+                         ids=["ragged", "37x50", "one", "two", "one-tile", "two-tiles", "56-rows"])
 def test_resident_mstep_helper_wavefronts_do_not_change_results(gpu, sizes):
     """Idle wavefronts of a workgroup take column blocks of the evaluations still running next to
     them (magma_set_option("resident_help", ...): 0 off, 1 on, 3 on with every compute unit
