@@ -67,6 +67,10 @@ int magma_prof_reset(void);
  * chain). "dag_workgroups": workgroups of the one-launch dense inverse (0 = launch-per-step
  * path). "dedup" (default 1): with identical timestamps and common hyper-parameters the driver
  * inverts K once per evaluation (Computing_functions.R:221-224, 347-350); 0 = batched sum.
+ * "resident_help" (default 1): in the device-resident M-step, wavefronts that find no individual
+ * left take tile rows of K and column blocks of the product stages of the evaluations still
+ * running in their workgroup (identical results; 0 = off; bit 1 = launch every compute unit even
+ * for a handful of individuals, for tests).
  * "dag_walker" (default 2): who walks the chain of diagonal tiles of the one-launch inverse -- 2: one
  * workgroup whose wavefronts work a block step ahead of the 64 x 64 factor, 1: one workgroup in
  * lock step, 0: a task per block step. "dag_max_block_rows" (default 64): the one-launch inverse
