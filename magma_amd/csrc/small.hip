@@ -695,6 +695,9 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
       }
     wave_sync();  // every load is issued before the sweep reuses the head of Ks
   } else {
+    // K is symmetric and (t_r - t_c)^2 = (t_c - t_r)^2 to the bit: only the tiles on and below the
+    // diagonal are computed (28 instead of 52 `exp` per lane at NMAX = 52); the tiles below it go
+    // to Ks transposed and the tiles above the diagonal are read back from there.
     double tcol[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
@@ -710,15 +713,32 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
         const int r = 16 * it + 4 * v + g;
         const double trow = tbuf[r];
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
+        for (int jt = 0; jt <= it; ++jt) {
           const int c = 16 * jt + l;
           const double d = trow - tcol[jt];
           double kv = exp(p.th1 - p.h * d * d);
           kv = (r == c) ? (p.eth1 + p.sig2) : kv;
           A[it][jt][v] = (r < n && c < n) ? kv : 0.0;
+          if (jt < it) Ks[c * LD + r] = A[it][jt][v];
           __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
         }
       }
+    }
+    if constexpr (NT > 1) {
+      wave_sync();
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (16 * it + 4 * v >= NMAX) continue;
+          const int r = 16 * it + 4 * v + g;
+#pragma unroll
+          for (int jt = it + 1; jt < NT; ++jt) {
+            const int c = 16 * jt + l;
+            A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
+          }
+        }
+      wave_sync();  // every load is issued before the sweep reuses the head of Ks
     }
   }
   if (mode == 1 && have_c) {  // K + C (C is zero in the padding)
