@@ -116,15 +116,32 @@ __device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParam
       const int r = 16 * it + 4 * v + g;
       const double trow = tbuf[r];
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
+      for (int jt = 0; jt <= it; ++jt) {  // tiles above the diagonal: by symmetry, see eval_factor
         const int c = 16 * jt + l;
         const double d = trow - tcol[jt];
         double kv = exp(p.th1 - p.h * d * d) * sc;
         kv = (r == c) ? 1.0 : kv;
         A[it][jt][v] = (r < n && c < n) ? kv : ((r == c) ? 1.0 : 0.0);
+        if (jt < it) Ks[c * LD + r] = A[it][jt][v];
         __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
       }
     }
+  }
+  if constexpr (NT > 1) {
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (16 * it + 4 * v >= NMAX) continue;
+        const int r = 16 * it + 4 * v + g;
+#pragma unroll
+        for (int jt = it + 1; jt < NT; ++jt) {
+          const int c = 16 * jt + l;
+          A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
+        }
+      }
+    wave_sync();  // every load is issued before the sweep reuses the head of Ks
   }
   double pm = 1.0;
   int pe = 0;
