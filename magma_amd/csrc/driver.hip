@@ -77,7 +77,9 @@ struct magma_ctx {
   ncclComm_t comm = nullptr;       // RCCL (world > 1), or
   magma_allreduce_fn cb = nullptr;  // a caller-supplied all-reduce
   void* cb_user = nullptr;
-  int reserve_cus = 64;  // compute units kept free of the resident M-step while theta_0 runs
+  // compute units kept free of the resident M-step while theta_0 runs (measured at C3: 64 / 80 /
+  // 88 / 96 / 104 / 112 -> 119.5 / 119.3 / 118.2 / 121.0 / 120.8 / 118.3 EM it/s, fit 55.7 -> 53.5 ms)
+  int reserve_cus = 96;
   int prefactor_wgs = 96;  // workgroups of the theta_0 inverse that runs next to the E-step's
   // workgroups of the monitoring call's inverse while the next E-step's sums run next to it (a
   // tile-graph workgroup fills its compute unit: with the full grid nothing else is dispatched

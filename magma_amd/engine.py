@@ -578,7 +578,7 @@ class Engine:
         # runs next to it (its workgroups fill whole compute units; the chain's dense inverse
         # needs whole free ones): the resident launch is capped at (CUs - reserve) workgroups and
         # the one-launch inverse at `reserve` for the duration of the M-step. 0 = no split.
-        self.reserve_cus = int(os.environ.get("MAGMA_RESERVE_CUS", 64))
+        self.reserve_cus = int(os.environ.get("MAGMA_RESERVE_CUS", 96))
         self._dag_wgs = int(os.environ.get("MAGMA_DAG_WGS", 256))
         # workgroups of the one-launch dense inverse (library default 256; 0 = launch-per-step path)
         if os.environ.get("MAGMA_DAG_WGS") is not None:
