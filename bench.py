@@ -332,6 +332,16 @@ def main():
                     "share_of_step_time": prof[dom]["share_of_step_time"]}
             if dom == "indiv_mstep(resident)":
                 roof["n_evals_per_launch"] = n_evals / nres
+                # the launch runs next to the theta_0 chain on its share of the chip (one workgroup
+                # per compute unit, MAGMA_RESERVE_CUS left free): `frac` prices it against the
+                # whole chip all the same
+                if not common:
+                    ncu = torch.cuda.get_device_properties(local).multi_processor_count
+                    res = int(os.environ.get("MAGMA_RESERVE_CUS", 96))
+                    if 0 < res < ncu:
+                        roof["compute_units_used"] = ncu - res
+                        roof["compute_units"] = ncu
+                        roof["frac_of_peak_of_units_used"] = prof[dom]["frac"] * ncu / (ncu - res)
         e0 = stats["theta0_evals"] / n_steps
         ei = (stats["common_evals"] if common else stats["indiv_rounds"]) / n_steps
         # the fit inside the timed trajectory: iterations up to the reference's stopping rule
