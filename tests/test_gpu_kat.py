@@ -5,24 +5,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from kat_common import run_kat, dataset, hp_of, KATS  # noqa: E402
-from oracle import magma_oracle as orc  # noqa: E402  (checker only)
+from kat_common import run_kat, dataset, hp_of  # noqa: E402
 
-# Relative tolerance on the per-dataset MSE: 1e-8 (north star) for well-conditioned problems.
-# The reference inverts with LAPACK LU, the HIP path with Cholesky; two backward-stable
-# algorithms agree to ~cond * eps, so datasets whose prior covariance K_0 is ill-conditioned
-# (a few stored models have |sigma| ~ 1e-2 and cond(K_0) up to 2e8) get 200 * eps * cond.
-TOL = {"KAT1": 1e-8, "KAT2": 1e-8, "KAT3": 1e-7, "KAT4": 1e-8}
-
-
-def _cond_k0(name, d):
-    data_name, hp_name, _, _, pen = KATS[name]
-    _, test, train = dataset(data_name, d)
-    hp = hp_of(hp_name, d)
-    if isinstance(pen, str):
-        pen = np.mean([v[2] for v in hp["theta_i"].values()])
-    grid = np.unique(np.concatenate([train["Timestamp"], test["Timestamp"]]))
-    return np.linalg.cond(orc.kern_to_cov(grid, orc.kernel, hp["theta_0"], pen)[1])
+# Relative tolerance on the per-dataset MSE: 1e-8 (north star) on every dataset of all four
+# result files. (Rounds 1-2 kept a 200 * eps * cond(K_0) bound for ill-conditioned stored models;
+# no dataset ever needed it -- worst 2.2e-9 -- so it is gone: it could only hide regressions.)
+TOL = 1e-8
 
 
 @pytest.fixture(scope="module")
@@ -39,19 +27,9 @@ def test_reference_results_reproduced_on_gpu(m, name):
     got, exp = run_kat(name, m.posterior_mu, m.pred_gp, m.kernel)
     rel = np.abs(got[:, 0] - exp[:, 0]) / np.abs(exp[:, 0])
     assert np.median(rel) < 1e-11, (name, np.median(rel))
-    loose = np.nonzero(rel >= TOL[name])[0] + 1
-    for d in loose:
-        lim = 200 * np.finfo(float).eps * _cond_k0(name, int(d))
-        assert rel[d - 1] < lim, (name, int(d), rel[d - 1], lim)
-    # how many datasets needed the cond(K_0)-scaled bound, and the worst error on each side of it
-    # (run with -s / -rP to see it; also kept in the JUnit/"passed" section of the report)
-    tight = rel[rel < TOL[name]]
-    print(f"{name}: {tight.size}/100 datasets within {TOL[name]:g} (worst {tight.max():.2e}); "
-          f"{loose.size} took the 200*eps*cond(K_0) bound"
-          + (f" (datasets {list(map(int, loose))}, worst rel err {rel[loose - 1].max():.2e})"
-             if loose.size else ""))
-    # at most a handful of stored models are that ill-conditioned
-    assert loose.size <= 5, (name, list(map(int, loose)))
+    print(f"{name}: worst relative error of the MSE over 100 datasets {rel.max():.2e} "
+          f"(dataset {int(np.argmax(rel)) + 1})")
+    assert rel.max() < TOL, (name, int(np.argmax(rel)) + 1, rel.max())
     # CI95 coverage is a count: identical unless a point sits within rounding of a band edge
     assert np.abs(got[:, 1] - exp[:, 1]).max() < 1e-9, name
 

@@ -510,7 +510,8 @@ def test_spd_inverse_is_bitwise_repeatable_next_to_other_work(gpu, N):
 def test_em_iteration_is_bitwise_repeatable_and_routes_agree(gpu):
     """Default E-step route ("gather": fixed summation order) makes a whole EM iteration
     repeatable bit for bit; the atomic route agrees with it to rounding, and both with the
-    oracle (flagged individuals included: they contribute nothing)."""
+    oracle (flagged individuals included: they contribute through the slow path, as
+    tryCatch(solve, ginv) does at CF:161)."""
     from magma_amd.engine import Dataset, Engine
     rng = np.random.default_rng(43)
     db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50])
