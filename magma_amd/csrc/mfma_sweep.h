@@ -206,6 +206,182 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
   }
 }
 
+// The same sweep on the tiles on and below the diagonal only (A symmetric; A[it][jt], jt <= it: 10
+// of 16 tiles and 10 of 16 MFMAs per block at NT = 4, 80 instead of 128 accumulator registers).
+// The row block B' = A[J,:] is needed in full: its part left of / on the diagonal tile is in
+// registers as before, its part right of it is column J of the tiles BELOW the diagonal tile,
+// which the 16 lanes holding those columns write to Pn transposed (Pn's layout [column][h] is what
+// the pivot block and the F' fragments are read from anyway) and every lane reads back as its B
+// fragment. The update is the same MFMA on the same operands for every tile that is kept, so the
+// result is that of the full sweep up to the rounding of the tiles above the diagonal, which the
+// full sweep computes separately and this one defines by symmetry.
+// Registers of rows beyond 4 NK are zero on entry and stay zero, like the columns beyond it.
+template <int NT, int NK>
+__device__ __forceinline__ void mfma_sweep_lower(v4d (&A)[NT][NT], double* Pn, int l, int g,
+                                                 double& pm, int& pe, int& info) {
+  double gm[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    gm[h] = (g == h) ? 1.0 : 0.0;
+    asm volatile("" : "+v"(gm[h]));
+  }
+  auto serial = [&](int b, double (&bq)[NT], double (&nf)[NT], auto&& hook) {
+    const int it0 = b >> 2, v0 = b & 3;
+    const bool dg = (l == 4 * v0 + g);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (jt > it0) continue;
+      bq[jt] = A[it0][jt][v0] - ((jt == it0 && dg) ? 1.0 : 0.0);
+      Pn[(16 * jt + l) * 4 + g] = bq[jt];
+    }
+    if ((l >> 2) == v0) {  // this lane holds one of the columns J of tile column it0
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        if (jt <= it0) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          Pn[(16 * jt + g + 4 * v) * 4 + (l & 3)] = A[jt][it0][v];  // (rows >= NR: zeros, written too)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    hook(0);
+    double p[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(4 * b + r) * 4 + 2]);
+      p[r][0] = lo.x; p[r][1] = lo.y; p[r][2] = hi.x; p[r][3] = hi.y;
+      p[r][r] += 1.0;
+    }
+    hook(1);
+    int bad = 0;
+    auto fix = [&](double d, int k) {
+      const bool ok = (d > 0.0) && (d < 1.7e308);
+      bad = (!ok && bad == 0) ? k + 1 : bad;
+      return d;
+    };
+    const double d0 = fix(p[0][0], 0);
+    const double r0 = fast_rcp(d0);
+    hook(2);
+    const double l10 = p[1][0] * r0, l20 = p[2][0] * r0, l30 = p[3][0] * r0;
+    const double p11 = fma(-l10, p[1][0], p[1][1]);
+    const double p21 = fma(-l20, p[1][0], p[2][1]);
+    const double p31 = fma(-l30, p[1][0], p[3][1]);
+    double p22 = fma(-l20, p[2][0], p[2][2]);
+    double p32 = fma(-l30, p[2][0], p[3][2]);
+    double p33 = fma(-l30, p[3][0], p[3][3]);
+    hook(3);
+    const double d1 = fix(p11, 1);
+    const double r1 = fast_rcp(d1);
+    hook(4);
+    const double l21 = p21 * r1, l31 = p31 * r1;
+    p22 = fma(-l21, p21, p22);
+    p32 = fma(-l31, p21, p32);
+    p33 = fma(-l31, p31, p33);
+    const double d2 = fix(p22, 2);
+    hook(5);
+    const double r2 = fast_rcp(d2);
+    const double l32 = p32 * r2;
+    p33 = fma(-l32, p32, p33);
+    const double d3 = fix(p33, 3);
+    hook(6);
+    const double r3 = fast_rcp(d3);
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -fma(l21, m10, l20);
+    const double m31 = -fma(l32, m21, l31);
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+    hook(7);
+    double D[4][4];
+    D[3][3] = r3;
+    D[3][2] = r3 * m32;
+    D[3][1] = r3 * m31;
+    D[3][0] = r3 * m30;
+    D[2][2] = fma(m32, D[3][2], r2);
+    D[2][1] = fma(m32, D[3][1], r2 * m21);
+    D[2][0] = fma(m32, D[3][0], r2 * m20);
+    D[1][1] = fma(m31, D[3][1], fma(m21, r2 * m21, r1));
+    D[1][0] = fma(m31, D[3][0], fma(m21, r2 * m20, r1 * m10));
+    D[0][0] = fma(m30, D[3][0], fma(m20, r2 * m20, fma(m10, r1 * m10, r0)));
+    D[0][1] = D[1][0]; D[0][2] = D[2][0]; D[0][3] = D[3][0];
+    D[1][2] = D[2][1]; D[1][3] = D[3][1]; D[2][3] = D[3][2];
+    hook(8);
+    info = (bad != 0 && info == 0) ? 4 * b + bad : info;
+    {
+      int e;
+      pm *= frexp(d0, &e); pe += e;
+      pm *= frexp(d1, &e); pe += e;
+      pm *= frexp(d2, &e); pe += e;
+      pm *= frexp(d3, &e); pe += e;
+      if ((b & 7) == 7) {
+        pm = frexp(pm, &e);
+        pe += e;
+      }
+    }
+    asm volatile("" : "+v"(pm), "+v"(pe), "+v"(info));
+    hook(9);
+    double dc[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      dc[h] = fma(gm[3], D[h][3], fma(gm[2], D[h][2], fma(gm[1], D[h][1], gm[0] * D[h][0])));
+    hook(10);
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const double2 lo = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4]);
+      const double2 hi = *reinterpret_cast<const double2*>(&Pn[(16 * it + l) * 4 + 2]);
+      nf[it] = -fma(hi.y, dc[3], fma(hi.x, dc[2], fma(lo.y, dc[1], lo.x * dc[0])));
+      if (it > it0) bq[it] = Pn[(16 * it + l) * 4 + g];  // B' right of the diagonal tile
+    }
+    __builtin_amdgcn_wave_barrier();  // Pn is rewritten by the next block
+    hook(11);
+  };
+  double bq[NT], nf[NT];
+  serial(0, bq, nf, [](int) {});
+#pragma unroll
+  for (int b = 0; b < NK; ++b) {
+    const int it0 = b >> 2, v0 = b & 3;
+    const bool dg = (l == 4 * v0 + g);
+    const int it1 = (b + 1 < NK) ? ((b + 1) >> 2) : it0;
+    // phase A: the tiles the next block's row block comes from -- tile row it1 left of / on the
+    // diagonal, tile column it1 below it
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int it = q < it1 ? it1 : q, jt = q < it1 ? q : it1;
+      A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nf[it], bq[jt], A[it][jt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase B: the other tiles, spread over the stages of the next block's serial part
+    constexpr int CNT = NT * (NT - 1) / 2;
+    auto issue = [&](int k) {
+      __builtin_amdgcn_sched_barrier(0);
+      int q = 0;
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int jt = 0; jt <= it; ++jt) {
+          if (it == it1 || jt == it1) continue;
+          if (q >= k * CNT / 12 && q < (k + 1) * CNT / 12)
+            A[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nf[it], bq[jt], A[it][jt], 0, 0, 0);
+          ++q;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (b + 1 < NK) {
+      double bq2[NT], nf2[NT];
+      serial(b + 1, bq2, nf2, issue);
+      A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        bq[jt] = bq2[jt];
+        nf[jt] = nf2[jt];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) issue(k);
+      A[it0][it0][v0] -= dg ? 2.0 : 0.0;
+    }
+  }
+}
+
 }  // namespace magma
 
 namespace magma {

@@ -660,24 +660,59 @@ __global__ __launch_bounds__(256) void update_inv_kernel(
 // shuffling: rows 4 kk .. 4 kk + 3 of a matrix held in accumulator layout ARE its B fragment
 // for k-block kk (register kk & 3 of the tiles in tile row kk >> 2).
 //
-//  1. K built in place (identity padded to NMAX, a multiple of 4).
-//  2. Inverse + log-det by a blocked symmetric sweep (Gauss-Jordan without pivoting on an SPD
-//     matrix; its pivots are the squares of the Cholesky diagonal, so log-det and the SPD test
-//     are those of a Cholesky). Block J = 4 pivots: with P = A[J,J], D = P^-1 (4 x 4, every
-//     lane redundantly, LDL'), the sweep is  A <- A - F' B'  - 2 I_J  with
-//       B' = A[J,:] with (P - I) in place of P   (registers: the identity above),
-//       F' = B''  D                               (B' through 2 KB of LDS to transpose it),
-//     which leaves A[i,J] = A[i,J] D, A[J,J] = -D and the Schur complement elsewhere: 16 MFMAs
-//     per block and 12 LDS instructions, instead of 4 x (26 broadcast reads + 52 FMAs).
+// Everything symmetric is kept as its tiles on and below the diagonal only (round 3): K and K^-1
+// in registers through the sweep (80 instead of 128 accumulator registers at NMAX = 52, 10 instead
+// of 16 MFMAs per pivot block: mfma_sweep_lower) and K^-1 in LDS (KL below: 16 KB instead of
+// 21.6 KB). Together with T = C K^-1 held whole (so that the packed C is streamed through eight
+// registers instead of sitting in 104) an evaluation fits 256 registers and 20 KB of LDS, and two
+// wavefronts share a SIMD: one's pivot chain, exp()s and LDS round trips run under the other's
+// MFMAs.
+//
+//  1. K built in place (identity padded to NMAX, a multiple of 4), lower tiles.
+//  2. Inverse + log-det by the blocked symmetric sweep (mfma_sweep.h): block J = 4 pivots,
+//     P = A[J,J], D = P^-1 (4 x 4, every lane redundantly, LDL'), A <- A - F' B' - 2 I_J.
 //     After NMAX / 4 blocks A = -K^-1.
-//  3. K^-1 -> LDS once (Ks; symmetric, so [k][j] and [j][k] fragment reads coincide).
+//  3. K^-1 -> LDS once (Ks, layout KL).
 //  4. T = C K^-1: A fragments straight from the packed C in global memory, B from Ks.
 //  5. Z = K^-1 T: A fragments from Ks, B fragments = T's registers; only tiles on or below the
 //     diagonal, each contracted with K_nl and dK/dtheta2 as soon as it is complete.
 // The evaluation comes in pieces so that the device-resident M-step can hand the column blocks of
 // stages 4 / 5 to other wavefronts of its workgroup (indiv_mstep_kernel); indiv_eval_body below
 // strings them together for one wavefront.
-//
+
+// K^-1 (or K on its way in) of one individual in LDS: the 16 x 16 tiles (it, jt), jt <= it, one after
+// the other by tile row, each tile row-major with a row stride of TS = 18 doubles. A fragment read
+// takes 4 rows x 16 columns of a tile (lanes: l along the row, g over the rows) or, for a tile
+// above the diagonal, 16 rows x 4 columns of its mirror image (l over the rows, g along them): with
+// a stride of 18 doubles = 36 banks the 32 lanes of a ds_read_b64 phase fall on 32 different bank
+// pairs in the second form and on all but two in the first.
+template <int NMAX>
+struct KL {
+  static constexpr int NT = (NMAX + 15) / 16;
+  static constexpr int TS = 18;
+  static constexpr int rows(int it) { return NMAX - 16 * it >= 16 ? 16 : NMAX - 16 * it; }
+  static constexpr int tb(int it, int jt) {  // first double of tile (it, jt), jt <= it
+    int s = 0;
+    for (int a = 0; a < it; ++a) s += (a + 1) * rows(a) * TS;
+    return s + jt * rows(it) * TS;
+  }
+  static constexpr int total = tb(NT - 1, NT - 1) + rows(NT - 1) * TS;
+  // (reads of a short last tile row in the second form run up to 15 * TS + 16 doubles past a tile:
+  // what they fetch only reaches masked results; callers keep that much LDS behind Ks)
+  static constexpr int alloc = total + 16;
+  static_assert(total >= 64 * NT, "the head of Ks doubles as the sweep's transposition buffer");
+};
+
+// K^-1[4 kk + g][16 jt + l] = K^-1[16 jt + l][4 kk + g]: the B fragment of k-block kk for tile
+// column jt, and the A fragment of tile row jt for k-block kk (kk, jt compile-time after unrolling).
+template <int NMAX>
+__device__ __forceinline__ double kinv_frag(const double* Ks, int kk, int jt, int l, int g) {
+  using L = KL<NMAX>;
+  const int kt = kk >> 2, kr = 4 * (kk & 3);
+  if (kt >= jt) return Ks[L::tb(kt, jt) + (kr + g) * L::TS + l];
+  return Ks[L::tb(jt, kt) + l * L::TS + kr + g];
+}
+
 // Stages 1-3: K(theta) (+ C in mode 1) -> K^-1 in Ks (LDS), log|K|, info. Ends with a wave_sync().
 // FROM_LDS: K (unscaled, zero beyond n) was put into Ks by eval_build_row, by this wavefront or by
 // others; stage 1 then only loads it.
@@ -686,35 +721,27 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
                                             const double* tbuf, double* Ks,
                                             const double* __restrict__ cpack, int mode,
                                             double& logdet, int& info_res) {
+  using L = KL<NMAX>;
   constexpr int NT = (NMAX + 15) / 16;  // 16 x 16 tiles per dimension
   constexpr int NK = NMAX / 4;          // blocks of 4 rows / k-blocks
-  constexpr int LD = NMAX;              // row length of Ks
   static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
   const int l = lane & 15, g = lane >> 4;
   const bool have_c = (cpack != nullptr);
   // packed C_i: Cq[kk * 64 * NT + it] = C[16 it + l][4 kk + g] (see indiv_gather_cov_kernel)
   const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
 
-  // ---- 1. K in accumulator layout (rows >= NMAX are never touched: compile-time skip)
+  // ---- 1. K in accumulator layout, tiles jt <= it (rows >= NMAX stay zero: compile-time skip)
   v4d A[NT][NT];
   if constexpr (FROM_LDS) {
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 16 * it + 4 * v + g;
+      for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          const int c = 16 * jt + l;
-          if (16 * it + 4 * v >= NMAX) A[it][jt][v] = 0.0;
-          else A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
-        }
-      }
+        for (int jt = 0; jt <= it; ++jt)
+          A[it][jt][v] = (16 * it + 4 * v < NMAX) ? Ks[L::tb(it, jt) + (4 * v + g) * L::TS + l] : 0.0;
     wave_sync();  // every load is issued before the sweep reuses the head of Ks
   } else {
-    // K is symmetric and (t_r - t_c)^2 = (t_c - t_r)^2 to the bit: only the tiles on and below the
-    // diagonal are computed (28 instead of 52 `exp` per lane at NMAX = 52); the tiles below it go
-    // to Ks transposed and the tiles above the diagonal are read back from there.
     double tcol[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
@@ -724,7 +751,7 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
       for (int v = 0; v < 4; ++v) {
         if (16 * it + 4 * v >= NMAX) {
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
+          for (int jt = 0; jt <= it; ++jt) A[it][jt][v] = 0.0;
           continue;
         }
         const int r = 16 * it + 4 * v + g;
@@ -736,39 +763,16 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
           double kv = exp(p.th1 - p.h * d * d);
           kv = (r == c) ? (p.eth1 + p.sig2) : kv;
           A[it][jt][v] = (r < n && c < n) ? kv : 0.0;
-          if (jt < it) Ks[c * LD + r] = A[it][jt][v];
           __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
         }
       }
     }
-    if constexpr (NT > 1) {
-      wave_sync();
-#pragma unroll
-      for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          if (16 * it + 4 * v >= NMAX) continue;
-          const int r = 16 * it + 4 * v + g;
-#pragma unroll
-          for (int jt = it + 1; jt < NT; ++jt) {
-            const int c = 16 * jt + l;
-            A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
-          }
-        }
-      wave_sync();  // every load is issued before the sweep reuses the head of Ks
-    }
   }
   if (mode == 1 && have_c) {  // K + C (C is zero in the padding)
-    double c1[NK][NT];
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
-      for (int it = 0; it < NT; ++it) c1[kk][it] = Cq[kk * 64 * NT + it];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk)
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) A[kk >> 2][jt][kk & 3] += c1[kk][jt];
+      for (int jt = 0; jt <= (kk >> 2); ++jt) A[kk >> 2][jt][kk & 3] += Cq[kk * 64 * NT + jt];
   }
   // Scale to a diagonal <= 1 (the sweep's operand trick is exact to rounding only for pivots
   // <= 1: mfma_sweep.h): K' = sc K, identity in the padding; K^-1 = sc K'^-1,
@@ -793,31 +797,27 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
       if (16 * it + 4 * v >= NMAX) continue;
       const int r = 16 * it + 4 * v + g;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
+      for (int jt = 0; jt <= it; ++jt) {
         const int c = 16 * jt + l;
         A[it][jt][v] = (r < n && c < n) ? A[it][jt][v] * sc : ((r == c) ? 1.0 : 0.0);
       }
     }
 
-  // ---- 2. blocked symmetric sweep (mfma_sweep.h)
+  // ---- 2. blocked symmetric sweep on the lower tiles (mfma_sweep.h)
   double pm = 1.0;
   int pe = 0, info = 0;
-  mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
+  mfma_sweep_lower<NT, NK>(A, Ks, l, g, pm, pe, info);
   logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
   info_res = info;
 
-  // ---- 3. K^-1 = -A to LDS
+  // ---- 3. K^-1 = -A to LDS (whole tiles: columns beyond NMAX are exact zeros)
 #pragma unroll
   for (int it = 0; it < NT; ++it)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       if (16 * it + 4 * v >= NMAX) continue;
-      const int r = 16 * it + 4 * v + g;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const int c = 16 * jt + l;
-        if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
-      }
+      for (int jt = 0; jt <= it; ++jt) Ks[L::tb(it, jt) + (4 * v + g) * L::TS + l] = -sc * A[it][jt][v];
     }
   wave_sync();
 }
@@ -826,31 +826,32 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
 template <int NMAX, int IT>
 __device__ __forceinline__ void eval_build_row(int lane, int n, const SEParams& p,
                                                const double* tbuf, double* Ks) {
-  constexpr int NT = (NMAX + 15) / 16, LD = NMAX;
+  using L = KL<NMAX>;
   const int l = lane & 15, g = lane >> 4;
-  double tcol[NT];
+  double tcol[IT + 1];
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
+  for (int jt = 0; jt <= IT; ++jt) tcol[jt] = tbuf[16 * jt + l];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     if (16 * IT + 4 * v >= NMAX) continue;
     const int r = 16 * IT + 4 * v + g;
     const double trow = tbuf[r];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
+    for (int jt = 0; jt <= IT; ++jt) {
       const int c = 16 * jt + l;
       const double d = trow - tcol[jt];
       double kv = exp(p.th1 - p.h * d * d);
       kv = (r == c) ? (p.eth1 + p.sig2) : kv;
-      if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = (r < n && c < n) ? kv : 0.0;
+      Ks[L::tb(IT, jt) + (4 * v + g) * L::TS + l] = (r < n && c < n) ? kv : 0.0;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-// The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52). (Left alone the compiler
-// issues them a pair at a time next to their uses: NK serial HBM latencies per wavefront; callers
-// put a sched_barrier on either side.)
+// The packed C_i as one batch of 16-byte loads (26 per lane at NMAX = 52): for the wavefronts
+// that work on single column blocks (helped evaluations). (Left alone the compiler issues them a
+// pair at a time next to their uses: NK serial HBM latencies per wavefront; callers put a
+// sched_barrier on either side.)
 template <int NMAX>
 __device__ __forceinline__ void eval_load_c(double (&cf)[NMAX / 4][(NMAX + 15) / 16],
                                             const double* __restrict__ cpack, int i, int lane) {
@@ -862,75 +863,135 @@ __device__ __forceinline__ void eval_load_c(double (&cf)[NMAX / 4][(NMAX + 15) /
     for (int it = 0; it < NT; ++it) cf[kk][it] = Cq[kk * 64 * NT + it];
 }
 
-// alpha = K^-1 z (lane r owns row r; column reads by symmetry); zero beyond NMAX.
+// alpha = K^-1 z (lane r owns row r: its part left of / on the diagonal tile read along the row,
+// the rest down column r of the tile rows below); zero beyond NMAX.
 template <int NMAX>
 __device__ __forceinline__ double eval_alpha(int lane, const double* Ks, const double* zbuf) {
-  constexpr int LD = NMAX;
-  double alpha = 0.0;
+  using L = KL<NMAX>;
+  constexpr int NT = L::NT, TS = L::TS;
   const int lr = lane < NMAX ? lane : 0;
+  const int rt = lr >> 4, rl = lr & 15;
+  const int rsz = ((rt == NT - 1) ? L::rows(NT - 1) : 16) * TS;  // one tile of this lane's tile row
+  const int base_r = 16 * TS * (rt * (rt + 1) / 2) + rl * TS;    // (every tile row above is full)
+  double alpha = 0.0;
 #pragma unroll
   for (int c = 0; c < NMAX; c += 2) {
     const double2 zz = *reinterpret_cast<const double2*>(&zbuf[c]);
-    alpha = fma(Ks[c * LD + lr], zz.x, alpha);
-    alpha = fma(Ks[(c + 1) * LD + lr], zz.y, alpha);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ct = (c + q) >> 4, cl = (c + q) & 15;
+      const int a_row = base_r + ct * rsz + cl;
+      const int a_col = L::tb(ct, 0) + rt * (L::rows(ct) * TS) + cl * TS + rl;
+      alpha = fma(Ks[rt >= ct ? a_row : a_col], q == 0 ? zz.x : zz.y, alpha);
+    }
   }
   return lane < NMAX ? alpha : 0.0;
 }
 
-// Stages 4 / 5 for column block JT: Tc = (C K^-1)[:, JT] (NT tiles), then Z[at][JT] = K^-1 Tc for
-// at >= JT, contracted at once with K_nl and dK/dtheta2. Returns THIS block's sums per lane,
-// started from zero: the caller adds the blocks in the order 0, 1, ..., whoever computed them, so
-// that every route gives the same bits. alpha (abuf) is first read after the products:
-// wait_alpha() is called in front of that read (a helper wavefront waits there for the owner).
+// Stage 4 for column block JT from a whole copy of the packed C: T[:, JT] = (C K^-1)[:, JT].
+template <int NMAX, int JT>
+__device__ __forceinline__ void eval_tblock(int lane, const double (&cf)[NMAX / 4][(NMAX + 15) / 16],
+                                            const double* Ks, v4d (&T)[(NMAX + 15) / 16][(NMAX + 15) / 16]) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  const int l = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int it = 0; it < NT; ++it) T[it][JT] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double bf = kinv_frag<NMAX>(Ks, 0, JT, l, g);
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const double b0 = bf;
+    if (kk + 1 < NK) bf = kinv_frag<NMAX>(Ks, kk + 1, JT, l, g);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+      T[it][JT] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[kk][it], b0, T[it][JT], 0, 0, 0);
+  }
+}
+
+// Stage 4 for all column blocks at once by one wavefront: the packed C is streamed through two
+// k-blocks' worth of registers (each k-block feeds 16 MFMAs = 1024 matrix-core cycles, far more
+// than the latency of the next one's two 16-byte loads). Every T[it][jt] accumulates its k-blocks in
+// the order eval_tblock uses: same bits.
+template <int NMAX>
+__device__ __forceinline__ void eval_tfull(int lane, int i, const double* __restrict__ cpack,
+                                           const double* Ks, v4d (&T)[(NMAX + 15) / 16][(NMAX + 15) / 16]) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  const int l = lane & 15, g = lane >> 4;
+  const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) T[it][jt] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double cn[NT], bn[NT];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) cn[it] = Cq[it];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) bn[jt] = kinv_frag<NMAX>(Ks, 0, jt, l, g);
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    double c0[NT], b0[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      c0[it] = cn[it];
+      b0[it] = bn[it];
+    }
+    if (kk + 1 < NK) {
+#pragma unroll
+      for (int it = 0; it < NT; ++it) cn[it] = Cq[(kk + 1) * 64 * NT + it];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) bn[jt] = kinv_frag<NMAX>(Ks, kk + 1, jt, l, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+        T[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[it], b0[jt], T[it][jt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Stage 5 for column block JT, given T[:, JT]: Z[at][JT] = K^-1 T[:, JT] for at >= JT, contracted at
+// once with K_nl and dK/dtheta2; tr(C K^-1)'s share is T's diagonal. Returns THIS block's sums per
+// lane, started from zero: callers reduce them over the wavefront and add the blocks in the order
+// 0, 1, ..., whoever computed them, so that every route gives the same bits. alpha (abuf) is first
+// read after the products: wait_alpha() is called in front of that read (a helper wavefront waits
+// there for the owner).
 template <int NMAX, int JT, class WaitAlpha>
-__device__ __forceinline__ void eval_block(int lane, int n, const SEParams& p, bool with_c,
-                                           const double (&cf)[NMAX / 4][(NMAX + 15) / 16],
-                                           const double* Ks, const double* tbuf, const double* abuf,
-                                           WaitAlpha&& wait_alpha, double& s1, double& s2,
-                                           double& s3, double& cor) {
-  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4, LD = NMAX;
+__device__ __forceinline__ void eval_zblock(int lane, int n, const SEParams& p, bool with_c,
+                                            const v4d (&T)[(NMAX + 15) / 16][(NMAX + 15) / 16],
+                                            const double* Ks, const double* tbuf, const double* abuf,
+                                            WaitAlpha&& wait_alpha, double& s1, double& s2,
+                                            double& s3, double& cor) {
+  using L = KL<NMAX>;
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
   constexpr int jt = JT;
   const int l = lane & 15, g = lane >> 4;
   s1 = 0.0;
   s2 = 0.0;
   s3 = 0.0;
   cor = 0.0;
-  v4d Tc[NT];
   v4d Z[NT];
 #pragma unroll
-  for (int it = 0; it < NT; ++it) {
-    Tc[it] = (v4d){0.0, 0.0, 0.0, 0.0};
-    Z[it] = (v4d){0.0, 0.0, 0.0, 0.0};
-  }
+  for (int it = 0; it < NT; ++it) Z[it] = (v4d){0.0, 0.0, 0.0, 0.0};
   if (with_c) {
-    double bf = Ks[g * LD + 16 * jt + l];
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      const double b0 = bf;
-      if (kk + 1 < NK) bf = Ks[(4 * (kk + 1) + g) * LD + 16 * jt + l];
-#pragma unroll
-      for (int it = 0; it < NT; ++it)
-        Tc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[kk][it], b0, Tc[it], 0, 0, 0);
-    }
     // tr(C K^-1): the diagonal of T sits in the diagonal tiles where g + 4v == l
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (16 * jt + 4 * v < NMAX) cor += (g + 4 * v == l) ? Tc[jt][v] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);
+      if (16 * jt + 4 * v < NMAX) cor += (g + 4 * v == l) ? T[jt][jt][v] : 0.0;
     double ka[NT];
 #pragma unroll
-    for (int at = jt; at < NT; ++at) ka[at] = Ks[g * LD + 16 * at + l];
+    for (int at = jt; at < NT; ++at) ka[at] = kinv_frag<NMAX>(Ks, 0, at, l, g);
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
       double k0[NT];
 #pragma unroll
       for (int at = jt; at < NT; ++at) {
         k0[at] = ka[at];
-        if (kk + 1 < NK) ka[at] = Ks[(4 * (kk + 1) + g) * LD + 16 * at + l];
+        if (kk + 1 < NK) ka[at] = kinv_frag<NMAX>(Ks, kk + 1, at, l, g);
       }
 #pragma unroll
       for (int at = jt; at < NT; ++at)
-        Z[at] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0[at], Tc[kk >> 2][kk & 3], Z[at], 0, 0, 0);
+        Z[at] = __builtin_amdgcn_mfma_f64_16x16x4f64(k0[at], T[kk >> 2][jt][kk & 3], Z[at], 0, 0, 0);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -950,7 +1011,7 @@ __device__ __forceinline__ void eval_block(int lane, int n, const SEParams& p, b
       const double gq = p.h * d * d;
       double knl = exp(p.th1 - gq);
       knl = (ra == cj) ? p.eth1 : knl;
-      const double W = fma(abuf[ra], acj, Z[at][v] - Ks[ra * LD + cj]);
+      const double W = fma(abuf[ra], acj, Z[at][v] - Ks[L::tb(at, jt) + (4 * v + g) * L::TS + l]);
       const double wt = (jt == at) ? 1.0 : 2.0;  // tiles above the diagonal by symmetry
       const double wk = ok ? wt * W * knl : 0.0;
       s1 += wk;
@@ -968,19 +1029,51 @@ __device__ __forceinline__ void for_blocks(F&& f) {
   if constexpr (JT + 1 < (NMAX + 15) / 16) for_blocks<NMAX, JT + 1>(f);
 }
 
-// f and the gradient from the per-lane sums of all column blocks (every lane returns the same).
+// A column block's sums over the wavefront (every lane gets the same): what the blocks' owners and
+// helpers exchange, four doubles per block.
+struct BlockSums {
+  double s1, s2, s3, cor;
+};
+__device__ __forceinline__ BlockSums block_reduce(double q1, double q2, double q3, double qc) {
+  BlockSums b;
+  b.s1 = wave_sum(q1);
+  b.s2 = wave_sum(q2);
+  b.s3 = wave_sum(q3);
+  b.cor = wave_sum(qc);
+  return b;
+}
+
+// f and the gradient from the sums of all column blocks (every lane returns the same).
 __device__ __forceinline__ void eval_finish(int n, double sigma, double logdet, double ssq,
-                                            int info, bool with_c, double s1, double s2, double s3,
+                                            int info, double s1, double s2, double s3,
                                             double cor, double& f_res, double (&g_res)[3]) {
   const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-  if (with_c) cor = wave_sum(cor);
   f_res = (info == 0) ? 0.5 * ((double)n * LOG_2PI + logdet + ssq) + 0.5 * cor : nanv;
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  s3 = wave_sum(s3);
   g_res[0] = (info == 0) ? -0.5 * s1 : nanv;
   g_res[1] = (info == 0) ? -0.5 * s2 : nanv;
   g_res[2] = (info == 0) ? -sigma * s3 : nanv;
+}
+
+// Stages 4 / 5 by one wavefront on its own. Returns the sums over all column blocks.
+template <int NMAX>
+__device__ __forceinline__ BlockSums eval_products(int lane, int n, int i, const SEParams& p,
+                                                   bool with_c, const double* __restrict__ cpack,
+                                                   const double* Ks, const double* tbuf,
+                                                   const double* abuf) {
+  constexpr int NT = (NMAX + 15) / 16;
+  v4d T[NT][NT];
+  if (with_c) eval_tfull<NMAX>(lane, i, cpack, Ks, T);
+  BlockSums tot = {0.0, 0.0, 0.0, 0.0};
+  for_blocks<NMAX>([&](auto JT) {
+    double q1, q2, q3, qc;
+    eval_zblock<NMAX, decltype(JT)::value>(lane, n, p, with_c, T, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
+    const BlockSums b = block_reduce(q1, q2, q3, qc);
+    tot.s1 += b.s1;
+    tot.s2 += b.s2;
+    tot.s3 += b.s3;
+    tot.cor += b.cor;
+  });
+  return tot;
 }
 
 // One evaluation at hyper-parameters (th1, th2, sigma) by this wavefront. tbuf / zbuf hold the
@@ -991,9 +1084,9 @@ __device__ __forceinline__ void indiv_eval_body(
     int lane, int n, int i, double th1, double th2, double sigma, const double* tbuf,
     const double* zbuf, double* abuf, double* Ks, const double* __restrict__ cpack, int mode,
     int want_grad, double& f_res, double (&g_res)[3], int& info_res) {
+  using L = KL<NMAX>;
   constexpr int NT = (NMAX + 15) / 16;
   constexpr int NK = NMAX / 4;
-  constexpr int LD = NMAX;
   const int l = lane & 15, g = lane >> 4;
   const SEParams p = se_params(th1, th2, sigma);
   const double zr = zbuf[lane];
@@ -1003,13 +1096,6 @@ __device__ __forceinline__ void indiv_eval_body(
   int info;
   eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
   STAMP(1);
-
-  // issued once the accumulator tiles are dead and consumed after alpha
-  __builtin_amdgcn_sched_barrier(0);
-  double cf[NK][NT];
-  if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
-  __builtin_amdgcn_sched_barrier(0);
-
   const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
   const double ssq = wave_sum(zr * alpha);
   STAMP(2);
@@ -1017,16 +1103,14 @@ __device__ __forceinline__ void indiv_eval_body(
   if (!want_grad) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     double cor = 0.0;
-    if (with_c) {  // sum(K^-1 o C) in accumulator layout, C read by symmetry
+    if (with_c) {  // sum(K^-1 o C) over the lower tiles (twice those below the diagonal)
+      const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          // columns >= NMAX of the last tile column read the next row / the unwritten tail of
-          // Ks: selected away (a product with the zero padding of C would turn a stale NaN
-          // bit pattern left in LDS by another kernel into a NaN result)
-          const double kv = Ks[(4 * kk + g) * LD + 16 * jt + l];
-          cor = fma((16 * jt + 15 < NMAX || 16 * jt + l < NMAX) ? kv : 0.0, cf[kk][jt], cor);
+        for (int jt = 0; jt <= (kk >> 2); ++jt) {
+          const double kv = Ks[L::tb(kk >> 2, jt) + (4 * (kk & 3) + g) * L::TS + l];
+          cor = fma(((kk >> 2) == jt ? 1.0 : 2.0) * kv, Cq[kk * 64 * NT + jt], cor);
         }
       cor = wave_sum(cor);
     }
@@ -1038,25 +1122,20 @@ __device__ __forceinline__ void indiv_eval_body(
   }
   abuf[lane] = alpha;
   wave_sync();  // abuf visible
-
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0;
-  for_blocks<NMAX>([&](auto JT) {
-    double q1, q2, q3, qc;
-    eval_block<NMAX, decltype(JT)::value>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
-    s1 += q1;
-    s2 += q2;
-    s3 += q3;
-    cor += qc;
-  });
+  const BlockSums t = eval_products<NMAX>(lane, n, i, p, with_c, cpack, Ks, tbuf, abuf);
   STAMP(7);
-  eval_finish(n, sigma, logdet, ssq, info, with_c, s1, s2, s3, cor, f_res, g_res);
+  eval_finish(n, sigma, logdet, ssq, info, t.s1, t.s2, t.s3, t.cor, f_res, g_res);
   info_res = info;
   STAMP(8);
   STAMP_FLUSH();
 }
 
+// Two wavefronts per SIMD where the instantiation's registers allow it (up to 52 rows).
 template <int NMAX>
-__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
+constexpr int indiv_eval_waves() { return NMAX <= 52 ? 2 : 1; }
+
+template <int NMAX>
+__global__ __launch_bounds__(64, MAGMA_INDIV_WAVES * indiv_eval_waves<NMAX>()) void indiv_eval_kernel(
     int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
@@ -1065,9 +1144,8 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES) void indiv_eval_kernel(
   __shared__ double tbuf[64];
   __shared__ double zbuf[64];
   __shared__ double abuf[64];
-  // Ks: NMAX * NMAX + 16 doubles (fragment reads of the last rows run up to 12 doubles past the
-  // end; what they fetch only reaches masked results). During the sweep its first 256 doubles
-  // are the transposition buffer Pn[64][4].
+  // Ks: KL<NMAX>::alloc doubles + slack for the fragment reads past a short last tile row. During
+  // the sweep its first 64 NT doubles are the transposition buffer Pn[64][4].
   extern __shared__ __attribute__((aligned(16))) double Ks[];
   const int lane = threadIdx.x;
   const int io = blockIdx.x;  // slot of theta / f / g / info (compact when sel is given)
@@ -1115,51 +1193,43 @@ __device__ __attribute__((noinline)) void lbfgsb_tell_device(lbcore::State<3, 5>
   else lbcore::tell_fixed<3, 0>(*st, f, g, factr, pgtol, maxit);
 }
 
-// Workgroups of four wavefronts, each wavefront an independent worker with its own slice of the
-// workgroup's LDS: with ~450 registers per lane a wavefront fills a SIMD's register file, so one
-// workgroup fills one compute unit, and a launch of G workgroups occupies G compute units and
-// leaves the others alone -- which is what the theta_0 chain's dense kernels running next to this
-// one need (the workgroups of the dense inverse want a whole free compute unit; with
-// one-wavefront workgroups spread over every SIMD of the chip they waited for the launch to
-// drain). Individuals are handed out through a ticket counter in the order given (longest
-// expected chain first): a wavefront that finishes a problem takes the next ticket.
+// Workgroups of RW wavefronts, each wavefront an independent worker with its own slice of the
+// workgroup's LDS. RW = 8 (two wavefronts per SIMD, 256 registers each) where eight slices fit the
+// compute unit's 160 KB, else 4 (one per SIMD, all 512 registers): either way one workgroup fills
+// one compute unit, and a launch of G workgroups occupies G compute units and leaves the others
+// alone -- which is what the theta_0 chain's dense kernels running next to this one need (the
+// workgroups of the dense inverse want a whole free compute unit). Individuals are handed out
+// through a ticket counter in the order given (longest expected chain first): a wavefront that
+// finishes a problem takes the next ticket.
 //
 // The tail. Which individuals need the long chains (100-200 evaluations against 5-8 on average)
 // is not known ahead, so the launch used to last as long as the longest chain on one wavefront
 // while the wavefronts next to it had nothing left to do. Now a wavefront that finds the tickets
-// gone becomes a HELPER of its workgroup. The owner of a running problem, once K^-1 is in its LDS
-// slice, opens its board: one claim word per column block of stages 4 / 5. Helpers and the owner
-// itself claim blocks (atomic exchange; block 0, the largest, first), each block's per-lane sums
-// go to the owner's LDS, and the owner adds them in block order -- the order a single wavefront
-// uses, so the result does not depend on who computed what. Helpers keep the packed C of the
-// individual they last worked for in registers. All control flow is wave-uniform and in straight
-// `if`s over compile-time block numbers (a run-time block number dispatched by a switch inside the
-// claim loop compiled into code that never left the loop). Every wait is bounded and raises the
-// workgroup's abort word, which turns the evaluation into a NaN (status 5 for that individual).
-constexpr int RES_WAVES = 4;
+// gone becomes a HELPER of its workgroup. The owner of a running problem opens its board: one claim
+// word per tile row of K and per column block of stages 4 / 5. Helpers and the owner itself claim
+// them (atomic exchange; block 0, the largest, first), each block's sums go to the owner's LDS,
+// and the owner adds them in block order -- the order a single wavefront uses, so the result does
+// not depend on who computed what. Helpers keep the packed C of the individual they last worked
+// for in registers. All control flow is wave-uniform and in straight `if`s over compile-time block
+// numbers (a run-time block number dispatched by a switch inside the claim loop compiled into code
+// that never left the loop). Every wait is bounded and raises the workgroup's abort word, which
+// turns the evaluation into a NaN (status 5 for that individual).
+constexpr int RES_WAVES_MAX = 8;
 constexpr int RC_NIDLE = 0, RC_ABORT = 1, RC_OWNER = 8, RC_STRIDE = 16;
 constexpr int RO_CLAIM = 0 /* .. 3 */, RO_DONE = 4, RO_AREADY = 5, RO_EPOCH = 6, RO_I = 7, RO_N = 8,
               RO_LEFT = 9, RO_BCLAIM = 10 /* .. 13 */, RO_BDONE = 14, RO_BLEFT = 15;
-constexpr int RC_WORDS = RC_OWNER + RC_STRIDE * RES_WAVES;
+constexpr int RC_WORDS = RC_OWNER + RC_STRIDE * RES_WAVES_MAX;
 constexpr unsigned long long RES_HELPER_LIMIT = 300000000ull;  // 3 s of the 100 MHz clock
 
-template <int NMAX>
-constexpr int resident_solo_doubles() {
-  return NMAX * NMAX + 16 + 3 * 64 + (int)((sizeof(lbcore::State<3, 5>) + 127) / 128) * 16;
-}
-template <int NMAX>
-constexpr int resident_part_doubles() {  // [block][s1, s2, s3, cor][lane]
-  return ((NMAX + 15) / 16) * 4 * 64;
-}
-// Helpers need 2 KB of LDS per column block and wavefront: there is room for that up to 56 rows.
-template <int NMAX>
-constexpr bool resident_help() {
-  return (size_t)RES_WAVES * (resident_solo_doubles<NMAX>() + resident_part_doubles<NMAX>()) *
-                 sizeof(double) + 2048 <= 160 * 1024;
-}
+// One wavefront's LDS slice: Ks, timestamps, residuals, alpha, optimiser state, the block sums
+// helpers leave ([block][s1, s2, s3, cor]).
 template <int NMAX>
 constexpr int resident_wave_doubles() {
-  return resident_solo_doubles<NMAX>() + (resident_help<NMAX>() ? resident_part_doubles<NMAX>() : 0);
+  return KL<NMAX>::alloc + 3 * 64 + (int)((sizeof(lbcore::State<3, 5>) + 127) / 128) * 16 + 16;
+}
+template <int NMAX>
+constexpr int resident_waves() {
+  return (size_t)8 * resident_wave_doubles<NMAX>() * sizeof(double) + 4096 <= 160 * 1024 ? 8 : 4;
 }
 
 // Control words in LDS: one lane writes, every lane gets the same (scalar) value back.
@@ -1181,8 +1251,8 @@ __device__ __forceinline__ bool ctl_claim(int* p, int lane) {  // true: the word
 
 // Diagnostics of a workgroup that gave up on a wait (first writer wins): [0] code (1 owner waiting
 // for block sums, 2 helper waiting for alpha, 3 helper loop beyond the time limit), [1] workgroup,
-// [2] wavefront, [3] idle count, then done / alpha-ready / epoch / blocks left of the four boards
-// (code 4: owner waiting for the tile rows of K).
+// [2] wavefront, [3] idle count, then done / alpha-ready / epoch / blocks left of the first four
+// boards (code 4: owner waiting for the tile rows of K).
 static __device__ unsigned long long g_res_diag[24];
 __device__ __noinline__ void resident_diag(int code, int wave, const int* s_ctl) {
   if ((threadIdx.x & 63) != 0) return;
@@ -1191,7 +1261,7 @@ __device__ __noinline__ void resident_diag(int code, int wave, const int* s_ctl)
   g_res_diag[2] = wave;
   g_res_diag[3] = __hip_atomic_load(s_ctl + RC_NIDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   const int words[4] = {RO_DONE, RO_AREADY, RO_EPOCH, RO_LEFT};
-  for (int o = 0; o < RES_WAVES; ++o)
+  for (int o = 0; o < 4; ++o)
     for (int q = 0; q < 4; ++q)
       g_res_diag[4 + 4 * o + q] = (unsigned long long)(unsigned)__hip_atomic_load(
           s_ctl + RC_OWNER + RC_STRIDE * o + words[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1214,6 +1284,28 @@ struct HelpedSums {
   double s1, s2, s3, cor, ssq, logdet;
   int info, ok;
 };
+// One claimed column block, by the owner or by a helper: T[:, jt] from the wavefront's copy of the
+// packed C, stage 5, the block's sums into the owner's slice.
+template <int NMAX, int JT, class WaitAlpha>
+__device__ __forceinline__ void resident_do_block(int lane, int n, const SEParams& p, bool with_c,
+                                                  const double (&cf)[NMAX / 4][(NMAX + 15) / 16],
+                                                  const double* Ks, const double* tbuf,
+                                                  const double* abuf, double* part,
+                                                  WaitAlpha&& wait_alpha) {
+  constexpr int NT = (NMAX + 15) / 16;
+  v4d T[NT][NT];
+  if (with_c) eval_tblock<NMAX, JT>(lane, cf, Ks, T);
+  double q1, q2, q3, qc;
+  eval_zblock<NMAX, JT>(lane, n, p, with_c, T, Ks, tbuf, abuf, wait_alpha, q1, q2, q3, qc);
+  const BlockSums b = block_reduce(q1, q2, q3, qc);
+  if (lane == 0) {
+    part[4 * JT + 0] = b.s1;
+    part[4 * JT + 1] = b.s2;
+    part[4 * JT + 2] = b.s3;
+    part[4 * JT + 3] = b.cor;
+  }
+}
+
 template <int NMAX>
 __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
     lds_double* Ks_, lds_int* s_ctl_, lds_double* s_par_, int wave, int lane, int n, int i, int epoch,
@@ -1222,10 +1314,10 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   double* Ks = (double*)Ks_;
   int* s_ctl = (int*)s_ctl_;
   double* s_parw = (double*)s_par_ + 4 * wave;
-  double* tbuf = Ks + NMAX * NMAX + 16;
+  double* tbuf = Ks + KL<NMAX>::alloc;
   double* zbuf = tbuf + 64;
   double* abuf = zbuf + 64;
-  double* part = Ks + resident_solo_doubles<NMAX>();
+  double* part = Ks + resident_wave_doubles<NMAX>() - 16;
   int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
   int* abort_ = s_ctl + RC_ABORT;
   const bool with_c = (cpack != nullptr);
@@ -1245,10 +1337,11 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   ctl_store(ctl + RO_BDONE, 0, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   ctl_store(ctl + RO_BLEFT, NT, lane);
+  // (the last tile row, the one with the most tiles, first)
 #pragma unroll
   for (int it = 0; it < NT; ++it) ctl_store(ctl + RO_BCLAIM + it, 0, lane);
   for_blocks<NMAX>([&](auto IT) {
-    constexpr int it = decltype(IT)::value;
+    constexpr int it = NT - 1 - decltype(IT)::value;
     if (ctl_claim(ctl + RO_BCLAIM + it, lane)) {
       eval_build_row<NMAX, it>(lane, n, p, tbuf, Ks);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1284,13 +1377,7 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   for_blocks<NMAX>([&](auto JT) {
     constexpr int jt = decltype(JT)::value;
     if (ctl_claim(ctl + RO_CLAIM + jt, lane)) {
-      double q1, q2, q3, qc;
-      eval_block<NMAX, jt>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
-      double* pj = part + jt * 256 + lane;
-      pj[0] = q1;
-      pj[64] = q2;
-      pj[128] = q3;
-      pj[192] = qc;
+      resident_do_block<NMAX, jt>(lane, n, p, with_c, cf, Ks, tbuf, abuf, part, [] {});
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       ctl_add(ctl + RO_LEFT, -1, lane);
       ctl_add(ctl + RO_DONE, 1, lane);
@@ -1305,11 +1392,10 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   r.s1 = r.s2 = r.s3 = r.cor = 0.0;
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
-    const double* pj = part + jt * 256 + lane;
-    r.s1 += pj[0];
-    r.s2 += pj[64];
-    r.s3 += pj[128];
-    r.cor += pj[192];
+    r.s1 += part[4 * jt + 0];
+    r.s2 += part[4 * jt + 1];
+    r.s3 += part[4 * jt + 2];
+    r.cor += part[4 * jt + 3];
   }
   r.ok = ok ? 1 : 0;
   wave_sync();
@@ -1321,7 +1407,7 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(256))) void indiv_mstep_kernel(
+__global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>() / 4) void indiv_mstep_kernel(
     int M, const int* __restrict__ order, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ mean, const double* __restrict__ cpack, int mode,
@@ -1331,22 +1417,20 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket,
     int help_on) {
   constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
-  constexpr bool HELP = resident_help<NMAX>();
+  constexpr int RW = resident_waves<NMAX>();
   static_assert(NT <= 4, "four claim words per board");
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   __shared__ int s_ctl[RC_WORDS];
-  __shared__ double s_par[RES_WAVES][4];
+  __shared__ double s_par[RES_WAVES_MAX][4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS bases in SGPRs
-  // this wavefront's LDS: Ks (NMAX^2 + 16; fragment reads of the last rows run up to 12 doubles
-  // past the end, into masked results), timestamps, residuals, alpha, optimiser state, block sums
   double* Ks = dyn + (size_t)wave * resident_wave_doubles<NMAX>();
-  double* tbuf = Ks + NMAX * NMAX + 16;
+  double* tbuf = Ks + KL<NMAX>::alloc;
   double* zbuf = tbuf + 64;
   double* abuf = zbuf + 64;
   lbcore::State<3, 5>* st = reinterpret_cast<lbcore::State<3, 5>*>(abuf + 64);
-  double* part = Ks + resident_solo_doubles<NMAX>();
   int* ctl = s_ctl + RC_OWNER + RC_STRIDE * wave;
   int* abort_ = s_ctl + RC_ABORT;
+  (void)ctl;
   if (threadIdx.x < RC_WORDS) {  // boards closed (every block claimed), everything else zero
     const int q = ((int)threadIdx.x - RC_OWNER) % RC_STRIDE;
     const bool claim = (q >= RO_CLAIM && q < RO_CLAIM + 4) || (q >= RO_BCLAIM && q < RO_BCLAIM + 4);
@@ -1388,48 +1472,34 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
     // Somebody idle in this workgroup? Then this evaluation goes on the board (mode 0 only: K
     // without C). Its code is a function of its own: sharing the code between the two cases costs
     // the one that runs alone 3 % -- spills and waits at the joins.
-    bool helped = false;
-    if constexpr (HELP) helped = help_on != 0 && mode == 0 && ctl_load(s_ctl + RC_NIDLE) > 0;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, cor = 0.0, ssq;
+    const bool helped = help_on != 0 && mode == 0 && ctl_load(s_ctl + RC_NIDLE) > 0;
+    BlockSums tot = {0.0, 0.0, 0.0, 0.0};
+    double ssq;
 #ifdef MAGMA_RES_STAMPS
     const unsigned long long rs_e0 = __builtin_readcyclecounter();
 #endif
     if (!helped) {
       eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
-      __builtin_amdgcn_sched_barrier(0);
-      double cf[NK][NT];
-      if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
-      __builtin_amdgcn_sched_barrier(0);
       const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
       ssq = wave_sum(zr * alpha);
       abuf[lane] = alpha;
       wave_sync();  // abuf visible
-      for_blocks<NMAX>([&](auto JT) {
-        double q1, q2, q3, qc;
-        eval_block<NMAX, decltype(JT)::value>(lane, n, p, with_c, cf, Ks, tbuf, abuf, [] {}, q1, q2, q3, qc);
-        s1 += q1;
-        s2 += q2;
-        s3 += q3;
-        cor += qc;
-      });
-    }
-    if constexpr (HELP) {
-      if (helped) {
-        ++epoch;
-        const HelpedSums r = resident_helped_eval<NMAX>((lds_double*)Ks, (lds_int*)s_ctl,
-                                                        (lds_double*)&s_par[0][0], wave, lane, n, i,
-                                                        epoch, p, zr, cpack);
-        s1 = r.s1;
-        s2 = r.s2;
-        s3 = r.s3;
-        cor = r.cor;
-        ssq = r.ssq;
-        logdet = r.logdet;
-        info = r.ok ? r.info : -999;
-      }
+      tot = eval_products<NMAX>(lane, n, i, p, with_c, cpack, Ks, tbuf, abuf);
+    } else {
+      ++epoch;
+      const HelpedSums r = resident_helped_eval<NMAX>((lds_double*)Ks, (lds_int*)s_ctl,
+                                                      (lds_double*)&s_par[0][0], wave, lane, n, i,
+                                                      epoch, p, zr, cpack);
+      tot.s1 = r.s1;
+      tot.s2 = r.s2;
+      tot.s3 = r.s3;
+      tot.cor = r.cor;
+      ssq = r.ssq;
+      logdet = r.logdet;
+      info = r.ok ? r.info : -999;
     }
     double f, g[3] = {0.0, 0.0, 0.0};
-    eval_finish(n, sigma, logdet, ssq, info, with_c, s1, s2, s3, cor, f, g);
+    eval_finish(n, sigma, logdet, ssq, info, tot.s1, tot.s2, tot.s3, tot.cor, f, g);
 
     fx0 = (st->nfev == 0) ? f : fx0;  // (a loop counter here makes hipcc peel the first pass)
     wave_sync();  // the body's LDS traffic is over before the state is stepped
@@ -1464,97 +1534,86 @@ __global__ __launch_bounds__(64 * RES_WAVES, 1) __attribute__((amdgpu_num_vgpr(2
   }
 
   // ---- no tickets left: help the wavefronts of this workgroup that still run a problem
-  if constexpr (HELP) {
-    if (help_on == 0) return;
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
-    ctl_add(s_ctl + RC_NIDLE, 1, lane);
-    int tag = -1;  // individual whose packed C is in cf
-    const unsigned long long t_idle = wall_clock64();  // 100 MHz
-    double cf[NK][NT];
+  if (help_on == 0) return;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  ctl_add(s_ctl + RC_NIDLE, 1, lane);
+  int tag = -1;  // individual whose packed C is in cf
+  const unsigned long long t_idle = wall_clock64();  // 100 MHz
+  double cf[NK][NT];
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk)
+  for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
-      for (int it = 0; it < NT; ++it) cf[kk][it] = 0.0;
+    for (int it = 0; it < NT; ++it) cf[kk][it] = 0.0;
 #pragma unroll 1
-    for (;;) {
-      if (ctl_load(abort_) != 0) break;
-      if (ctl_load(s_ctl + RC_NIDLE) >= RES_WAVES) break;
-      bool did = false;
+  for (;;) {
+    if (ctl_load(abort_) != 0) break;
+    if (ctl_load(s_ctl + RC_NIDLE) >= RW) break;
+    bool did = false;
 #pragma unroll 1
-      for (int q = 1; q < RES_WAVES; ++q) {
-        const int o = (wave + q) & (RES_WAVES - 1);
-        int* co = s_ctl + RC_OWNER + RC_STRIDE * o;
-        double* oKs = dyn + (size_t)o * resident_wave_doubles<NMAX>();
-        const double* otbuf = oKs + NMAX * NMAX + 16;
-        const double* oabuf = otbuf + 128;
-        double* opart = oKs + resident_solo_doubles<NMAX>();
-        if (ctl_load(co + RO_BLEFT) > 0) {  // tile rows of K
-          for_blocks<NMAX>([&](auto IT) {
-            constexpr int it = decltype(IT)::value;
-            if (ctl_claim(co + RO_BCLAIM + it, lane)) {
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-              const int on = ctl_load(co + RO_N);
-              SEParams p;
-              p.th1 = s_par[o][0];
-              p.h = s_par[o][1];
-              p.sig2 = s_par[o][2];
-              p.eth1 = s_par[o][3];
-              eval_build_row<NMAX, it>(lane, on, p, otbuf, oKs);
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-              ctl_add(co + RO_BLEFT, -1, lane);
-              ctl_add(co + RO_BDONE, 1, lane);
-              did = true;
-            }
-          });
-        }
-        if (ctl_load(co + RO_LEFT) <= 0) continue;
-        for_blocks<NMAX>([&](auto JT) {
-          constexpr int jt = decltype(JT)::value;
-          if (ctl_claim(co + RO_CLAIM + jt, lane)) {
+    for (int q = 1; q < RW; ++q) {
+      const int o = (wave + q) & (RW - 1);
+      int* co = s_ctl + RC_OWNER + RC_STRIDE * o;
+      double* oKs = dyn + (size_t)o * resident_wave_doubles<NMAX>();
+      const double* otbuf = oKs + KL<NMAX>::alloc;
+      const double* oabuf = otbuf + 128;
+      double* opart = oKs + resident_wave_doubles<NMAX>() - 16;
+      if (ctl_load(co + RO_BLEFT) > 0) {  // tile rows of K
+        for_blocks<NMAX>([&](auto IT) {
+          constexpr int it = NT - 1 - decltype(IT)::value;
+          if (ctl_claim(co + RO_BCLAIM + it, lane)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const int oi = ctl_load(co + RO_I);
             const int on = ctl_load(co + RO_N);
-            const int oe = ctl_load(co + RO_EPOCH);
             SEParams p;
             p.th1 = s_par[o][0];
             p.h = s_par[o][1];
             p.sig2 = s_par[o][2];
             p.eth1 = s_par[o][3];
-            if (with_c && tag != oi) {
-              __builtin_amdgcn_sched_barrier(0);
-              eval_load_c<NMAX>(cf, cpack, oi, lane);
-              __builtin_amdgcn_sched_barrier(0);
-              tag = oi;
-            }
-            double q1, q2, q3, qc;
-            eval_block<NMAX, jt>(
-                lane, on, p, with_c, cf, oKs, otbuf, oabuf,
-                [&] {
-                  if (!lds_wait_ge(co + RO_AREADY, oe, abort_)) resident_diag(2, wave, s_ctl);
-                },
-                q1, q2, q3, qc);
-            double* pj = opart + jt * 256 + lane;
-            pj[0] = q1;
-            pj[64] = q2;
-            pj[128] = q3;
-            pj[192] = qc;
+            eval_build_row<NMAX, it>(lane, on, p, otbuf, oKs);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            ctl_add(co + RO_LEFT, -1, lane);
-            ctl_add(co + RO_DONE, 1, lane);
+            ctl_add(co + RO_BLEFT, -1, lane);
+            ctl_add(co + RO_BDONE, 1, lane);
             did = true;
           }
         });
       }
-      if (!did) {
-        // (nothing in this launch lasts seconds: a helper that has waited that long gives up)
-        if (wall_clock64() - t_idle > RES_HELPER_LIMIT) {
-          resident_diag(3, wave, s_ctl);
-          ctl_store(abort_, 1, lane);
-          break;
+      if (ctl_load(co + RO_LEFT) <= 0) continue;
+      for_blocks<NMAX>([&](auto JT) {
+        constexpr int jt = decltype(JT)::value;
+        if (ctl_claim(co + RO_CLAIM + jt, lane)) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          const int oi = ctl_load(co + RO_I);
+          const int on = ctl_load(co + RO_N);
+          const int oe = ctl_load(co + RO_EPOCH);
+          SEParams p;
+          p.th1 = s_par[o][0];
+          p.h = s_par[o][1];
+          p.sig2 = s_par[o][2];
+          p.eth1 = s_par[o][3];
+          if (with_c && tag != oi) {
+            __builtin_amdgcn_sched_barrier(0);
+            eval_load_c<NMAX>(cf, cpack, oi, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            tag = oi;
+          }
+          resident_do_block<NMAX, jt>(lane, on, p, with_c, cf, oKs, otbuf, oabuf, opart, [&] {
+            if (!lds_wait_ge(co + RO_AREADY, oe, abort_)) resident_diag(2, wave, s_ctl);
+          });
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          ctl_add(co + RO_LEFT, -1, lane);
+          ctl_add(co + RO_DONE, 1, lane);
+          did = true;
         }
-        __builtin_amdgcn_s_sleep(4);
+      });
+    }
+    if (!did) {
+      // (nothing in this launch lasts seconds: a helper that has waited that long gives up)
+      if (wall_clock64() - t_idle > RES_HELPER_LIMIT) {
+        resident_diag(3, wave, s_ctl);
+        ctl_store(abort_, 1, lane);
+        break;
       }
+      __builtin_amdgcn_s_sleep(4);
     }
   }
 }
@@ -1850,12 +1909,15 @@ static int launch_indiv_eval_t(int nsel, const int* sel, const int64_t* off, con
                                const double* y, const int* idx, const double* theta, int tstride,
                                const double* mean, const double* cpack, int mode, int want_grad,
                                double* f, double* g, int* info, hipStream_t st) {
-  const size_t dyn = ((size_t)NM * NM + 16) * sizeof(double);  // >= the 64 NT doubles of Pn
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    attr_set = true;
+  // Ks + what the fragment reads of a short last tile row run past it (KL)
+  const size_t dyn = ((size_t)KL<NM>::alloc + 16 * KL<NM>::TS) * sizeof(double);
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load()) {
+    if (int rc = check_hip(hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                           "indiv_eval LDS size"))
+      return rc;
+    attr_set.store(true);
   }
   hipLaunchKernelGGL(indiv_eval_kernel<NM>, dim3(nsel), dim3(64), dyn, st, nsel, sel, off, t, y,
                      idx, theta, tstride, mean, cpack, mode, want_grad, f, g, info);
@@ -1938,7 +2000,8 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
                                 const double* theta0, int lm, double factr, double pgtol,
                                 int maxit, double* theta_out, double* f_out, double* fx0_out,
                                 int* iters, int* nfev, int* status, hipStream_t st) {
-  const size_t dyn = (size_t)RES_WAVES * resident_wave_doubles<NM>() * sizeof(double);
+  constexpr int RW = resident_waves<NM>();
+  const size_t dyn = (size_t)RW * resident_wave_doubles<NM>() * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     if (int rc = check_hip(hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
@@ -1951,10 +2014,10 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
   if (int rc = resident_ticket(&ticket, st)) return rc;
   const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
   const int cus = device_compute_units();
-  int grid = (M + RES_WAVES - 1) / RES_WAVES;
+  int grid = (M + RW - 1) / RW;
   if (grid > cus || (g_resident_help.load(std::memory_order_relaxed) & 2)) grid = cus;  // persistent: one workgroup fills a compute unit
   if (cap > 0 && grid > cap) grid = cap;
-  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RES_WAVES), dyn, st, M, order, off,
+  hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RW), dyn, st, M, order, off,
                      t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out,
                      fx0_out, iters, nfev, status, ticket, g_resident_help.load(std::memory_order_relaxed) & 1);
   return check_hip(hipGetLastError(), "indiv_mstep");
