@@ -288,7 +288,11 @@ void magma_dataset_destroy(magma_dataset* ds);
 int magma_dataset_info(const magma_dataset* ds, int64_t* h_M, int* h_nmax, int* h_N, int* h_Np);
 int magma_dataset_grid(const magma_dataset* ds, double* h_grid /* N */);
 /* device pointers of the resident results, for hosts that chain the kernel-level entry points:
- * "mean" (Np), "cov" (Np x Np), "m0", "grid", "w", "work"; NULL for an unknown name */
+ * "mean" (Np), "cov" (Np x Np), "m0", "grid", "w", "work"; NULL for an unknown name. Valid until
+ * the NEXT driver call on this dataset only: an E-step may swap "cov" / "w" with the buffers of
+ * its prefetched sums (which the following EM iteration overwrites asynchronously), so ask again
+ * after every driver call instead of caching them; writing into "work" discards the K_0^-1 a
+ * following E-step would have reused (it is recomputed, results do not change). */
 void* magma_dataset_buffer(const magma_dataset* ds, const char* name);
 int magma_get_mean(magma_ctx* ctx, magma_dataset* ds, double* h_mean /* N */);
 int magma_get_cov(magma_ctx* ctx, magma_dataset* ds, double* h_cov /* N x N, ld */, int64_t ld);
@@ -334,7 +338,11 @@ int magma_training(magma_ctx* ctx, magma_dataset* ds, const double* h_m0, int n_
                    double* h_theta_i_out, int* h_converged, int* h_iterations, double* h_trace3);
 /* posterior_mu (MG:107-133): the dataset on t_pred = sort(unique(db U extra timestamps)) (built
  * here) and the E-step with `pen_diag` on it (MG:116 uses 0.1); *out keeps mean / cov resident
- * for magma_pred_gp_resident / magma_get_*; h_N = size of t_pred (magma_dataset_grid gives it). */
+ * for magma_pred_gp_resident / magma_get_*; h_N = size of t_pred (magma_dataset_grid gives it).
+ * With world > 1 the grid is the union over the WHOLE db, as in the reference: the ranks exchange
+ * their shards' unique timestamps first (two all-reduces), so every rank must make this call (it
+ * is collective), with the same h_extra_t or any split of it; a disagreement on the resulting grid
+ * is status 2, raised before the precision sums are exchanged. */
 int magma_posterior_mu(magma_ctx* ctx, magma_dataset** out, int64_t M, int64_t M_total, int64_t row0,
                        const int64_t* h_off, const double* h_t, const double* h_y, int64_t n_extra,
                        const double* h_extra_t, const double* h_theta0, const double* h_theta_i,

@@ -772,7 +772,10 @@ void* magma_dataset_buffer(const magma_dataset* d, const char* name) {
   if (s == "cov") return d->P.p;
   if (s == "m0") return d->m0.p;
   if (s == "grid") return d->grid.p;
-  if (s == "work") return d->work.p;
+  if (s == "work") {  // (the caller may write into it: the cached K_0^-1 is no longer trusted)
+    const_cast<magma_dataset*>(d)->a0_valid = false;
+    return d->work.p;
+  }
   if (s == "w") return d->w.p;
   return nullptr;
 }
@@ -920,7 +923,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if ((rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
     d->covfac_ok = true;
   }
-  if (d->M > 0) {  // individuals whose K_i was not positive definite (they contributed nothing)
+  if (d->M > 0) {  // individuals whose K_i was not positive definite (they took the solve() / ginv() slow path)
     if (!d->h_flag)
       MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_flag, sizeof(int) * (size_t)d->M, hipHostMallocDefault));
     MAGMA_CHECK_HIP(hipMemcpyAsync(d->h_flag, d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
@@ -1301,7 +1304,10 @@ int magma_posterior_mu(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M_t
                        int theta_stride, double pen_diag, const double* h_m0_scalar, int* h_N,
                        int* h_info) {
   if (!c || !out || !h_theta0 || !h_theta_i || !h_m0_scalar) return fail(2, "posterior_mu: NULL argument");
-  // t_pred = sort(unique(timestamps U db U new_db)) (MG:114)
+  // t_pred = sort(unique(timestamps U db U new_db)) (MG:114): the union over the WHOLE db. With
+  // several ranks each holds a shard of db, so the ranks' sorted unique timestamps are exchanged
+  // first (an all-gather through the all-reduce: every rank writes its block of a zeroed buffer)
+  // and every rank builds the same grid; the sizes of the collectives that follow depend on it.
   std::vector<double> grid;
   const int64_t R = M > 0 ? h_off[M] : 0;
   grid.reserve((size_t)(R + n_extra));
@@ -1309,6 +1315,48 @@ int magma_posterior_mu(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M_t
   if (n_extra > 0) grid.insert(grid.end(), h_extra_t, h_extra_t + n_extra);
   std::sort(grid.begin(), grid.end());
   grid.erase(std::unique(grid.begin(), grid.end()), grid.end());
+  if (c->has_comm() && c->world > 1) {
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = c->main;
+    DevBuf cnt;
+    std::vector<double> hc((size_t)c->world, 0.0);
+    hc[(size_t)c->rank] = (double)grid.size();
+    if (int rc = upload(cnt, hc)) return rc;
+    if (int rc = c->allreduce(cnt.as<double>(), c->world, st)) return rc;
+    if (int rc = d2h(hc.data(), cnt.p, sizeof(double) * hc.size(), st)) return rc;
+    if (int rc = sync(st)) return rc;
+    int64_t tot = 0, mine = 0;
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) mine = tot;
+      tot += (int64_t)hc[(size_t)r];
+    }
+    std::vector<double> all((size_t)std::max<int64_t>(tot, 1), 0.0);
+    std::copy(grid.begin(), grid.end(), all.begin() + mine);
+    DevBuf ga;
+    if (int rc = upload(ga, all)) return rc;
+    if (int rc = c->allreduce(ga.as<double>(), tot, st)) return rc;
+    if (int rc = d2h(all.data(), ga.p, sizeof(double) * (size_t)tot, st)) return rc;
+    if (int rc = sync(st)) return rc;
+    all.resize((size_t)tot);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    grid.swap(all);
+    // every rank must now hold the same grid: N and a checksum, checked before any P / w collective
+    // (sum over ranks of x and of x^2 equal world x and world x^2 only if all x are equal)
+    double chk = 0.0;
+    for (double g : grid) chk += g;
+    std::vector<double> q = {(double)grid.size(), (double)grid.size() * (double)grid.size(), chk, chk * chk};
+    DevBuf dq;
+    if (int rc = upload(dq, q)) return rc;
+    if (int rc = c->allreduce(dq.as<double>(), 4, st)) return rc;
+    std::vector<double> qs(4);
+    if (int rc = d2h(qs.data(), dq.p, sizeof(double) * 4, st)) return rc;
+    if (int rc = sync(st)) return rc;
+    const double w = (double)c->world;
+    auto near = [](double a, double b) { return std::fabs(a - b) <= 1e-9 * std::max(1.0, std::fabs(b)); };
+    if (!near(qs[0], w * q[0]) || !near(qs[1], w * q[1]) || !near(qs[2], w * q[2]) || !near(qs[3], w * q[3]))
+      return fail(2, "posterior_mu: the ranks disagree on the prediction grid (different n_extra / h_extra_t?)");
+  }
   if (grid.empty()) return fail(2, "posterior_mu: no timestamps");
   magma_dataset* d = nullptr;
   if (int rc = magma_dataset_create(c, &d, M, M_total, row0, h_off, h_t, h_y, (int)grid.size(), grid.data()))

@@ -57,10 +57,15 @@ __device__ __forceinline__ unsigned long long stamp_now() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+// inside eval_factor (slots 10 = build, 11 = sweep, 12 = K^-1 store)
+#define FSTAMP_INIT() unsigned long long fs_prev = stamp_now()
+#define FSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long fs_t = stamp_now(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[i], fs_t - fs_prev); fs_prev = fs_t; __builtin_amdgcn_sched_barrier(0);} while (0)
 #else
 #define STAMP_INIT()
 #define STAMP(i)
 #define STAMP_FLUSH()
+#define FSTAMP_INIT()
+#define FSTAMP(i)
 #endif
 
 // ------------------------------------------------------------------ K1: covariance only
@@ -731,6 +736,7 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
   const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
 
   // ---- 1. K in accumulator layout, tiles jt <= it (rows >= NMAX stay zero: compile-time skip)
+  FSTAMP_INIT();
   v4d A[NT][NT];
   if constexpr (FROM_LDS) {
 #pragma unroll
@@ -804,9 +810,11 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
     }
 
   // ---- 2. blocked symmetric sweep on the lower tiles (mfma_sweep.h)
+  FSTAMP(10);
   double pm = 1.0;
   int pe = 0, info = 0;
   mfma_sweep_lower<NT, NK>(A, Ks, l, g, pm, pe, info);
+  FSTAMP(11);
   logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
   info_res = info;
 
@@ -820,6 +828,7 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
       for (int jt = 0; jt <= it; ++jt) Ks[L::tb(it, jt) + (4 * v + g) * L::TS + l] = -sc * A[it][jt][v];
     }
   wave_sync();
+  FSTAMP(12);
 }
 
 // Tile row IT of K (mode 0: no C), unscaled, as eval_factor's stage 1 computes it, into Ks.
@@ -907,13 +916,30 @@ __device__ __forceinline__ void eval_tblock(int lane, const double (&cf)[NMAX / 
   }
 }
 
-// Stage 4 for all column blocks at once by one wavefront: the packed C is streamed through two
-// k-blocks' worth of registers (each k-block feeds 16 MFMAs = 1024 matrix-core cycles, far more
-// than the latency of the next one's two 16-byte loads). Every T[it][jt] accumulates its k-blocks in
-// the order eval_tblock uses: same bits.
+// Stage 4 for all column blocks at once by one wavefront: the packed C is streamed through a ring
+// of CDEPTH k-blocks' worth of registers (each k-block feeds 16 MFMAs = 1024 matrix-core cycles;
+// a 16-byte load that misses L2 takes a few thousand cycles with every compute unit streaming, so
+// the loads run CDEPTH k-blocks ahead; eval_cstream_start issues the first ones before alpha is
+// formed). Every T[it][jt] accumulates its k-blocks in the order eval_tblock uses: same bits.
+constexpr int CDEPTH = 4;
+template <int NMAX>
+struct CStream {
+  double ring[CDEPTH][(NMAX + 15) / 16];
+};
+template <int NMAX>
+__device__ __forceinline__ void eval_cstream_start(CStream<NMAX>& cs, int lane, int i,
+                                                   const double* __restrict__ cpack) {
+  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
+  const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
+#pragma unroll
+  for (int d = 0; d < CDEPTH; ++d)
+#pragma unroll
+    for (int it = 0; it < NT; ++it) cs.ring[d][it] = (d < NK) ? Cq[d * 64 * NT + it] : 0.0;
+}
 template <int NMAX>
 __device__ __forceinline__ void eval_tfull(int lane, int i, const double* __restrict__ cpack,
-                                           const double* Ks, v4d (&T)[(NMAX + 15) / 16][(NMAX + 15) / 16]) {
+                                           CStream<NMAX>& cs, const double* Ks,
+                                           v4d (&T)[(NMAX + 15) / 16][(NMAX + 15) / 16]) {
   constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
   const int l = lane & 15, g = lane >> 4;
   const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
@@ -921,9 +947,7 @@ __device__ __forceinline__ void eval_tfull(int lane, int i, const double* __rest
   for (int it = 0; it < NT; ++it)
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) T[it][jt] = (v4d){0.0, 0.0, 0.0, 0.0};
-  double cn[NT], bn[NT];
-#pragma unroll
-  for (int it = 0; it < NT; ++it) cn[it] = Cq[it];
+  double bn[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) bn[jt] = kinv_frag<NMAX>(Ks, 0, jt, l, g);
 #pragma unroll
@@ -931,12 +955,14 @@ __device__ __forceinline__ void eval_tfull(int lane, int i, const double* __rest
     double c0[NT], b0[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-      c0[it] = cn[it];
+      c0[it] = cs.ring[kk % CDEPTH][it];
       b0[it] = bn[it];
     }
-    if (kk + 1 < NK) {
+    if (kk + CDEPTH < NK) {
 #pragma unroll
-      for (int it = 0; it < NT; ++it) cn[it] = Cq[(kk + 1) * 64 * NT + it];
+      for (int it = 0; it < NT; ++it) cs.ring[kk % CDEPTH][it] = Cq[(kk + CDEPTH) * 64 * NT + it];
+    }
+    if (kk + 1 < NK) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) bn[jt] = kinv_frag<NMAX>(Ks, kk + 1, jt, l, g);
     }
@@ -1058,11 +1084,11 @@ __device__ __forceinline__ void eval_finish(int n, double sigma, double logdet, 
 template <int NMAX>
 __device__ __forceinline__ BlockSums eval_products(int lane, int n, int i, const SEParams& p,
                                                    bool with_c, const double* __restrict__ cpack,
-                                                   const double* Ks, const double* tbuf,
-                                                   const double* abuf) {
+                                                   CStream<NMAX>& cs, const double* Ks,
+                                                   const double* tbuf, const double* abuf) {
   constexpr int NT = (NMAX + 15) / 16;
   v4d T[NT][NT];
-  if (with_c) eval_tfull<NMAX>(lane, i, cpack, Ks, T);
+  if (with_c) eval_tfull<NMAX>(lane, i, cpack, cs, Ks, T);
   BlockSums tot = {0.0, 0.0, 0.0, 0.0};
   for_blocks<NMAX>([&](auto JT) {
     double q1, q2, q3, qc;
@@ -1096,6 +1122,11 @@ __device__ __forceinline__ void indiv_eval_body(
   int info;
   eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
   STAMP(1);
+  // the first k-blocks of the packed C: in flight while alpha is formed
+  __builtin_amdgcn_sched_barrier(0);
+  CStream<NMAX> cs;
+  if (with_c && want_grad) eval_cstream_start<NMAX>(cs, lane, i, cpack);
+  __builtin_amdgcn_sched_barrier(0);
   const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
   const double ssq = wave_sum(zr * alpha);
   STAMP(2);
@@ -1105,12 +1136,18 @@ __device__ __forceinline__ void indiv_eval_body(
     double cor = 0.0;
     if (with_c) {  // sum(K^-1 o C) over the lower tiles (twice those below the diagonal)
       const double* Cq = cpack + (int64_t)i * (16 * NT * NMAX) + lane * NT;
+      double cl[NK][NT];  // one batch of loads (left alone: one memory latency per k-block)
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+        for (int jt = 0; jt <= (kk >> 2); ++jt) cl[kk][jt] = Cq[kk * 64 * NT + jt];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
         for (int jt = 0; jt <= (kk >> 2); ++jt) {
           const double kv = Ks[L::tb(kk >> 2, jt) + (4 * (kk & 3) + g) * L::TS + l];
-          cor = fma(((kk >> 2) == jt ? 1.0 : 2.0) * kv, Cq[kk * 64 * NT + jt], cor);
+          cor = fma(((kk >> 2) == jt ? 1.0 : 2.0) * kv, cl[kk][jt], cor);
         }
       cor = wave_sum(cor);
     }
@@ -1122,7 +1159,7 @@ __device__ __forceinline__ void indiv_eval_body(
   }
   abuf[lane] = alpha;
   wave_sync();  // abuf visible
-  const BlockSums t = eval_products<NMAX>(lane, n, i, p, with_c, cpack, Ks, tbuf, abuf);
+  const BlockSums t = eval_products<NMAX>(lane, n, i, p, with_c, cpack, cs, Ks, tbuf, abuf);
   STAMP(7);
   eval_finish(n, sigma, logdet, ssq, info, t.s1, t.s2, t.s3, t.cor, f_res, g_res);
   info_res = info;
@@ -1480,11 +1517,15 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
 #endif
     if (!helped) {
       eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, cpack, mode, logdet, info);
+      __builtin_amdgcn_sched_barrier(0);
+      CStream<NMAX> cs;
+      if (with_c) eval_cstream_start<NMAX>(cs, lane, i, cpack);
+      __builtin_amdgcn_sched_barrier(0);
       const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
       ssq = wave_sum(zr * alpha);
       abuf[lane] = alpha;
       wave_sync();  // abuf visible
-      tot = eval_products<NMAX>(lane, n, i, p, with_c, cpack, Ks, tbuf, abuf);
+      tot = eval_products<NMAX>(lane, n, i, p, with_c, cpack, cs, Ks, tbuf, abuf);
     } else {
       ++epoch;
       const HelpedSums r = resident_helped_eval<NMAX>((lds_double*)Ks, (lds_int*)s_ctl,

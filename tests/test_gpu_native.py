@@ -268,6 +268,82 @@ def test_rccl_communicator_with_one_rank(m):
     rccl.close()
 
 
+def test_posterior_mu_grid_is_the_union_over_all_ranks(m):
+    """t_pred = sort(unique(db U new_db U timestamps)) is the union over the WHOLE db
+    (MG:114). Two and three ranks as threads whose shards hold DISJOINT timestamps, each passing
+    only a part of the extra timestamps: every rank must end with the one-rank grid, mean and cov."""
+    import ctypes as C
+    from magma_amd import _lib
+    from magma_amd.native import ALLREDUCE_FN
+    rng = np.random.default_rng(11)
+    sizes = [9, 14, 7, 12, 10, 8]
+    ids, ts, ys = [], [], []
+    for k, n in enumerate(sizes):  # individual k on its own residue class of a 0.01 lattice: disjoint
+        t = np.sort(rng.choice(np.arange(k, 600, len(sizes)), n, replace=False)) * 0.01
+        ids += [k + 1] * n
+        ts.append(t)
+        ys.append(rng.normal(0, 1, n) + t)
+    db = {"ID": np.array(ids), "Timestamp": np.concatenate(ts), "Output": np.concatenate(ys)}
+    ds = m.Dataset(db)
+    extra = np.array([0.005, 2.505, 5.995, 3.333])
+    th0 = np.array([0.8, 0.6])
+    thi = np.tile([0.7, 0.5, 0.3], (ds.M, 1)) + rng.uniform(-0.1, 0.1, (ds.M, 3))
+    hp = {"theta_0": th0, "theta_i": {i: thi[k] for k, i in enumerate(ds.ids)}}
+    ref = orc.posterior_mu(db, {"Timestamp": extra[:2]}, extra[2:], 0.3, orc.kernel, orc.kernel, hp)
+    hpv = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    m0 = np.array([0.3])
+
+    for world in (2, 3):
+        shared = _Shared(world)
+        out, errs = [None] * world, []
+
+        def work(r):
+            try:
+                import torch
+                torch.cuda.set_device(0)
+                ar = _make_allreduce(shared, r)
+
+                def cb(user, ptr, count, stream):
+                    ar(ptr, count)
+                    return 0
+                keep = ALLREDUCE_FN(cb)
+                ctx, dset = C.c_void_p(0), C.c_void_p(0)
+                _lib.call("magma_ctx_create_callback", C.byref(ctx), 0, r, world, C.cast(keep, C.c_void_p), None)
+                per = (ds.M + world - 1) // world
+                lo, hi = min(ds.M, r * per), min(ds.M, r * per + per)
+                o0, o1 = int(ds.off[lo]), int(ds.off[hi])
+                off = np.ascontiguousarray(ds.off[lo:hi + 1] - o0, dtype=np.int64)
+                t, y = np.ascontiguousarray(ds.t[o0:o1]), np.ascontiguousarray(ds.y[o0:o1])
+                mine = np.ascontiguousarray(extra[r::world])  # a split of the extra timestamps
+                N, info = C.c_int(0), C.c_int(0)
+                _lib.call("magma_posterior_mu", ctx, C.byref(dset), hi - lo, ds.M, lo, hpv(off), hpv(t), hpv(y),
+                          mine.size, hpv(mine), hpv(th0), hpv(np.ascontiguousarray(thi)), 3, 0.1, hpv(m0),
+                          C.byref(N), C.byref(info))
+                grid, mean = np.empty(N.value), np.empty(N.value)
+                cov = np.empty((N.value, N.value))
+                _lib.call("magma_dataset_grid", dset, hpv(grid))
+                _lib.call("magma_get_mean", ctx, dset, hpv(mean))
+                _lib.call("magma_get_cov", ctx, dset, hpv(cov), N.value)
+                out[r] = (info.value, grid, mean, cov)
+                _lib.load().magma_dataset_destroy(dset)
+                _lib.load().magma_ctx_destroy(ctx)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+                shared.barrier.abort()
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        if errs:
+            raise errs[0]
+        for info, grid, mean, cov in out:
+            assert info == 0 and np.array_equal(grid, ref["cov"][0])
+            assert np.abs(cov - ref["cov"][1]).max() < 1e-9 * np.abs(ref["cov"][1]).max()
+            assert np.abs(mean - ref["mean"]["Output"]).max() < 1e-9 * np.abs(ref["mean"]["Output"]).max()
+            assert np.array_equal(cov, out[0][3]) and np.array_equal(mean, out[0][2])
+
+
 # ------------------------------------------------------------------ prediction side
 def test_native_posterior_mu_pred_gp_and_train_new_gp(m):
     import ctypes as C
