@@ -53,21 +53,24 @@ PROF_NAMES = ["gemm_nt(T=Kinv*C)", "theta0_contract", "spd_inverse", "indiv_eval
 
 def pmc_traffic(kernel_class, args):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
-    THIS command line (profiles/r02_pmc_<config>_<steps>_<warmup>.json, made by
+    THIS command line (profiles/r03_pmc_<config>_<steps>_<warmup>.json, made by
     profiles/profile_round.sh: FETCH_SIZE and WRITE_SIZE collected in separate runs; counters in
     KB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced loads on gfx950).
     Counters cannot be read inside a timed run; a file made with other --steps / --warmup /
     --config is not used: then the figure is null."""
-    name = f"r02_pmc_{args.config}_{args.steps}_{args.warmup}.json"
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    keys = {"indiv_mstep(resident)": "magma::indiv_mstep_kernel<52>",
+    prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    name = next((f"{tag}_pmc_{args.config}_{args.steps}_{args.warmup}.json" for tag in ("r03", "r02")
+                 if os.path.exists(os.path.join(prof_dir, f"{tag}_pmc_{args.config}_{args.steps}_{args.warmup}.json"))),
+                None)
+    keys = {"indiv_mstep(resident)": "magma::indiv_mstep_kernel<",
             "spd_inverse": "magma::spd_inverse_dag_kernel",
             "gemm_nt(T=Kinv*C)": "magma::gemm_nt_kernel"}
-    if kernel_class not in keys or not os.path.exists(path):
+    if kernel_class not in keys or name is None:
         return None, None
+    path = os.path.join(prof_dir, name)
     with open(path) as fh:
         pmc = json.load(fh)
-    key = keys[kernel_class]
+    key = next((k for k in pmc.get("FETCH_SIZE", {}) if k.startswith(keys[kernel_class])), None)
     try:
         kb = 2.0 * pmc["FETCH_SIZE"][key]["avg_kb"] + pmc["WRITE_SIZE"][key]["avg_kb"]
     except KeyError:
@@ -146,11 +149,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (MAGMA_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks --
+    # every rank on GPU local % device_count, the launcher's collectives on gloo / CPU tensors, the
+    # EM's all-reduces through the library's callback communicator staged through the host)
+    backend = os.environ.get("MAGMA_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
+    ctl = "cuda" if backend == "nccl" else "cpu"  # where the launcher-level control tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from magma_amd import _lib
     from magma_amd.engine import Dataset
@@ -170,43 +183,73 @@ def main():
     a = simu_arrays(M_total, cfg["n"], cfg["N"], cfg["common_times"], cfg["common_hp"],
                     seed=cfg["seed"])
     ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
-    uid = None
-    if world > 1:
-        # the library's own RCCL communicator: rank 0's unique id, handed round by the launcher's
-        # process group; every collective of the EM then runs inside libmagma_hip.so
-        box = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            box.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
-        dist.broadcast(box, 0)
-        uid = bytes(box.cpu().numpy().tobytes())
     comm_kind = "none" if world == 1 else "rccl (inside libmagma_hip.so)"
-    eng = None
-    if world > 1 and os.environ.get("MAGMA_BENCH_COMM", "rccl") == "rccl":
-        try:
-            eng = NativeEngine(ds, rank=rank, world=world, unique_id=uid,
-                               device=torch.device("cuda", local))
-        except _lib.MagmaHipError as e:  # e.g. librccl not resolvable by dlopen on this box
-            print(f"[bench rank {rank}] RCCL communicator inside the library failed: {e}", file=sys.stderr)
-        ok = torch.tensor([1 if eng is not None else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and eng is not None:
-            eng.close()
-            eng = None
-    if eng is None and world > 1:
-        # fallback: the library's callback communicator on the launcher's process group (same EM
-        # code path; the sum itself is then torch.distributed's all_reduce on RCCL)
-        from magma_amd.native import device_tensor
-        comm_kind = "callback -> torch.distributed all_reduce (RCCL)"
+    dev = torch.device("cuda", local)
 
-        def allreduce(ptr, count, stream=None):
-            torch.cuda.synchronize()
-            tens = device_tensor(ptr, count)
-            dist.all_reduce(tens)
-            torch.cuda.synchronize()
-        eng = NativeEngine(ds, rank=rank, world=world, allreduce=allreduce,
-                           device=torch.device("cuda", local))
-    elif eng is None:
-        eng = NativeEngine(ds, rank=rank, world=world, device=torch.device("cuda", local))
+    def make_engine(dataset, note=None):
+        """This rank's engine on `dataset` with the job's communicator: the library's own RCCL
+        communicator, checked with a known vector on both of the library's streams before anything
+        is timed (magma_ctx_selfcheck: polled against a deadline, never a blocking wait); if RCCL
+        cannot be created inside the library, or sums wrongly, the library's callback communicator
+        on the launcher's process group takes over (same EM code path; reported in
+        config.communicator). A collective that does not complete leaves a blocked stream behind:
+        reported, exit code 3 -- a process that has touched the GPU is never replaced by another."""
+        nonlocal comm_kind
+        if world == 1:
+            return NativeEngine(dataset, rank=rank, world=world, device=dev)
+        e = None
+        if (os.environ.get("MAGMA_BENCH_COMM", "rccl") == "rccl" and backend == "nccl"
+                and not comm_kind.startswith("callback")):
+            box = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                try:
+                    box.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
+                except _lib.MagmaHipError as err:
+                    print(f"[bench] ncclGetUniqueId inside the library failed: {err}", file=sys.stderr)
+            dist.broadcast(box, 0)
+            uid = bytes(box.cpu().numpy().tobytes())
+            status = 1
+            if any(uid):
+                try:
+                    e = NativeEngine(dataset, rank=rank, world=world, unique_id=uid, device=dev)
+                    e.selfcheck(int(os.environ.get("MAGMA_BENCH_COMM_TIMEOUT_MS", "30000")))
+                    status = 0
+                except _lib.MagmaHipError as err:
+                    print(f"[bench rank {rank}] RCCL communicator inside the library: {err}", file=sys.stderr)
+                    status = 2 if "did not complete" in str(err) else 1
+            worst = torch.tensor([status], device="cuda")
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            if int(worst.item()) == 2:
+                print(f"[bench rank {rank}] a collective of the self-check never completed; giving up", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+            if int(worst.item()) != 0:
+                if e is not None:
+                    e.close()
+                e = None
+        if e is None:
+            from magma_amd.native import device_tensor
+            if backend == "nccl":
+                comm_kind = ("callback -> torch.distributed all_reduce (RCCL)" +
+                             ("" if os.environ.get("MAGMA_BENCH_COMM", "rccl") != "rccl" else
+                              "; the library's own communicator failed its self-check"))
+            else:
+                comm_kind = f"callback -> torch.distributed all_reduce ({backend}, staged through the host: rehearsal)"
+
+            def allreduce(ptr, count, stream=None):
+                torch.cuda.synchronize()
+                tens = device_tensor(ptr, count)
+                if backend == "nccl":
+                    dist.all_reduce(tens)
+                else:
+                    host = tens.cpu()
+                    dist.all_reduce(host)
+                    tens.copy_(host)
+                torch.cuda.synchronize()
+            e = NativeEngine(dataset, rank=rank, world=world, allreduce=allreduce, device=dev)
+            e.selfcheck(30000)
+        return e
+    eng = make_engine(ds)
     common = cfg["common_hp"]
     ini0, ini_i = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (ds.M, 1))
 
@@ -251,7 +294,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.magma_prof_enable(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -286,10 +329,39 @@ def main():
     rates["m_step_counts"] = {"sweeps_per_m_step": sweeps, "theta0_evals_per_m_step": st_m["theta0_evals"] / 4.0}
     rates["logL_monitoring_per_s"] = rate(lambda: eng.logL_monitoring(theta0, theta_i))
 
+    # BASELINE config 5 (M = 100,000 x 40 points, N = 2,000) sharded over the ranks of this job: the
+    # scale-out workload, as an extra key next to the headline (which stays the weak-scaling c3 line
+    # so that the per-N values the driver compares are one workload). A few EM iterations from the
+    # initial hyper-parameters, timed like the headline.
+    scale_out = None
+    if world > 1 and args.config == "c3" and os.environ.get("MAGMA_BENCH_SCALE_OUT", "1") == "1":
+        c5 = dict(CONFIGS["c5"])
+        a5 = simu_arrays(int(os.environ.get("MAGMA_BENCH_SCALE_OUT_M", "100000")), c5["n"], c5["N"], False, False,
+                         seed=c5["seed"])
+        ds5 = Dataset.from_arrays(a5["off"], a5["t"], a5["y"], grid=a5["grid"])
+        eng5 = make_engine(ds5)
+        t5, ti5 = ini0.copy(), np.tile([1.0, 1.0, 0.2], (ds5.M, 1))
+        t5, ti5, _, _ = eng5.em_iteration(t5, ti5, 0.0, False)
+        t5, ti5 = ini0.copy(), np.tile([1.0, 1.0, 0.2], (ds5.M, 1))
+        k5 = 3
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k5):
+            t5, ti5, _, _ = eng5.em_iteration(t5, ti5, 0.0, False)
+        barrier()
+        el5 = time.perf_counter() - t1
+        tt = torch.tensor([el5], dtype=torch.float64, device=ctl)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        scale_out = {"workload": f"c5: M={ds5.M} individuals x {c5['n']} points in total, sharded {world} ways "
+                                 f"({eng5.hi - eng5.lo} per GPU), N={c5['N']}, individual hyper-parameters",
+                     "scaling": "strong", "steps": k5, "ms_per_step": 1e3 * float(tt.item()) / k5,
+                     "value": k5 * (ds5.M / 10000.0) / float(tt.item()), "unit": "EM it/s (10k-task units)"}
+        eng5.close()
+
     if rank == 0:
         N, n, Mloc = cfg["N"], cfg["n"], eng.hi - eng.lo
         covfac = world == 1 and "cov_factor=0" not in os.environ.get("MAGMA_OPTIONS", "").replace(" ", "")
-        units = M_total / 10000.0 if args.config == "c3" else 1.0
+        units = M_total / 10000.0 if args.config in ("c3", "c5") else 1.0
         value = n_steps * units / elapsed
         S2 = Mloc * n ** 2
         nres = max(1, prof.get("indiv_mstep(resident)", {}).get("launches", 1))
@@ -379,6 +451,8 @@ def main():
             "roofline": roof, "fit": fit, "steady_state": steady, "rates": rates,
             "kernel_classes": prof,
         }
+        if scale_out is not None:
+            out["scale_out_c5"] = scale_out
         if not args.no_cpu_baseline and world == 1:
             t0c = time.time()
             cb = cpu_baseline(cfg)

@@ -280,6 +280,12 @@ int magma_ctx_create_callback(magma_ctx** out, int device, int rank, int world,
 void magma_ctx_destroy(magma_ctx* ctx);
 int magma_ctx_info(const magma_ctx* ctx, int* h_rank, int* h_world, int* h_device);
 void* magma_ctx_stream(const magma_ctx* ctx); /* the main stream (hipStream_t) */
+/* No counterpart in the reference (R is single-process): sends a known vector through the context's
+ * communicator on both of the library's streams and checks the sums; the streams are polled against
+ * `timeout_ms` rather than synchronised, so that a collective that never completes is status 211
+ * (report and exit: the stream stays blocked) and a wrong sum 212. 0 without a communicator. Every
+ * rank must call it (it is collective). bench.py runs it before it times anything. */
+int magma_ctx_selfcheck(magma_ctx* ctx, int timeout_ms);
 
 int magma_dataset_create(magma_ctx* ctx, magma_dataset** out, int64_t M, int64_t M_total,
                          int64_t row0, const int64_t* h_off, const double* h_t, const double* h_y,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "magma_ctx_destroy": (None, [_p]),
     "magma_ctx_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "magma_ctx_stream": (_p, [_p]),
+    "magma_ctx_selfcheck": (_i, [_p, _i]),
     "magma_dataset_create": (_i, [_p, C.POINTER(_p), _i64, _i64, _i64, _p, _p, _p, _i, _p]),
     "magma_dataset_destroy": (None, [_p]),
     "magma_dataset_info": (_i, [_p, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

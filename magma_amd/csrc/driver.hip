@@ -604,6 +604,50 @@ int magma_ctx_info(const magma_ctx* c, int* rank, int* world, int* device) {
 
 void* magma_ctx_stream(const magma_ctx* c) { return c ? (void*)c->main : nullptr; }
 
+// A known vector through the context's communicator on both of the library's streams, before a
+// job trusts it with an EM: every rank contributes (rank + 1) x {1, 2, ..., 64} and must get
+// world (world + 1) / 2 times that back. RCCL collectives are asynchronous: the streams are polled
+// against the deadline instead of synchronised, so a collective that never completes (a rank that
+// did not join, a transport that is not up) comes back as status 211 with the process still in
+// control (the stream stays blocked: the caller should report and exit, not go on).
+int magma_ctx_selfcheck(magma_ctx* c, int timeout_ms) {
+  if (!c) return fail(2, "ctx is NULL");
+  if (!c->has_comm()) return 0;
+  if (int rc = set_device(c)) return rc;
+  constexpr int NV = 64;
+  std::vector<double> h((size_t)NV);
+  for (int k = 0; k < NV; ++k) h[(size_t)k] = (double)(c->rank + 1) * (double)(k + 1);
+  const double want = 0.5 * (double)c->world * (double)(c->world + 1);
+  hipStream_t streams[2] = {c->main, c->side};
+  const char* names[2] = {"main", "side"};
+  for (int q = 0; q < 2; ++q) {
+    DevBuf b;
+    if (int rc = upload(b, h)) return rc;
+    if (int rc = c->allreduce(b.as<double>(), NV, streams[q])) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(streams[q]);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return check_hip(e, "selfcheck stream query");
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > (double)timeout_ms) {
+        b.p = nullptr;  // (the collective may still write into it: leaked on purpose)
+        return fail(211, std::string("communicator self-check: the all-reduce on the ") + names[q] +
+                             " stream did not complete within " + std::to_string(timeout_ms) + " ms");
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    std::vector<double> r((size_t)NV);
+    MAGMA_CHECK_HIP(hipMemcpy(r.data(), b.p, sizeof(double) * NV, hipMemcpyDeviceToHost));
+    for (int k = 0; k < NV; ++k)
+      if (r[(size_t)k] != want * (double)(k + 1))
+        return fail(212, std::string("communicator self-check: wrong sum on the ") + names[q] + " stream (element " +
+                             std::to_string(k) + ": " + std::to_string(r[(size_t)k]) + ", expected " +
+                             std::to_string(want * (double)(k + 1)) + ")");
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------ dataset
 int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M_total, int64_t row0,
                          const int64_t* h_off, const double* h_t, const double* h_y, int N,
@@ -741,8 +785,12 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
         return rc;
     }
   }
-  MAGMA_CHECK_HIP(hipMemset(d->mean.p, 0, sizeof(double) * Np));
-  MAGMA_CHECK_HIP(hipMemset(d->m0.p, 0, sizeof(double) * Np));
+  // (on the context's stream and waited for: hipMemset runs on the null stream, which the library's
+  // non-blocking streams do not wait for -- with other threads keeping the null stream busy it
+  // could land after the first set_m0 and wipe the prior mean)
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->mean.p, 0, sizeof(double) * Np, c->main));
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->m0.p, 0, sizeof(double) * Np, c->main));
+  if ((rc = sync(c->main))) return rc;
   *out = guard.release();
   return 0;
 }
@@ -880,9 +928,13 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
       return rc;
     int linfo = 0;
     if ((rc = d2h(&linfo, li, sizeof(int), st)) || (rc = sync(st))) return rc;
-    if (linfo != 0) {  // (the solve() / ginv() slow path covers n_i <= 64 only: left out, counted)
+    if (linfo != 0) {
+      // The solve() / ginv() slow path (CF:161) covers n_i <= 64 only. Leaving this individual out
+      // of the hyper-posterior would be a silent deviation from the reference: an error instead.
       d->stats.flagged += 1;
-      continue;
+      return fail(5, "E-step: K_i of an individual with more than 64 observations is not positive definite "
+                     "(local row " + std::to_string(L->row) + ", info=" + std::to_string(linfo) +
+                     "); the pseudo-inverse route exists for n_i <= 64 only");
     }
     if ((rc = magma_copy_unpad(L->n, d->LK.as<double>(), d->LKc.as<double>(), L->n, st)) ||
         (rc = launch_update_inv(1, L->off.as<int64_t>(), d->zero2.as<int64_t>(), L->idx.as<int>(),
@@ -1005,7 +1057,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if (int rc = sync(st)) return rc;
     if (int rc = count_flagged(d, st, false)) return rc;
     const bool split = !common_hp && c->reserve_cus > 0 && M > 0;
-    set_resident_max_workgroups(split ? std::max(1, c->ncu - c->reserve_cus) : 0);
+    set_resident_max_workgroups_thread(split ? std::max(1, c->ncu - c->reserve_cus) : -1);
     th0 = std::thread(run0);
   }
   bool joined = false;
@@ -1013,7 +1065,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if (th0.joinable()) th0.join();
     if (!joined) {
       joined = true;
-      set_resident_max_workgroups(0);
+      set_resident_max_workgroups_thread(-1);
       d->stats.theta0_evals += nfev0;
     }
     if (rc0) return fail(rc0, err0);

@@ -1867,6 +1867,22 @@ __global__ __launch_bounds__(64) void pred_gp_batched_kernel(
     else { CALL(64); }                                  \
   } while (0)
 
+// hipFuncSetAttribute is per device and the library may be driven by one thread per GPU: the
+// guard is one atomic flag per device and kernel instantiation (setting it twice is harmless).
+struct AttrOnce {
+  std::atomic<bool> done[64];
+  AttrOnce() { for (auto& d : done) d.store(false); }
+  template <class F>
+  int ensure(F&& set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev].load(std::memory_order_acquire)) return 0;
+    if (int rc = set()) return rc;
+    done[dev].store(true, std::memory_order_release);
+    return 0;
+  }
+};
+
 int launch_se_cov_batched(int M, const int64_t* off, const int64_t* off2, const double* t,
                           const double* theta, int tstride, double* out, hipStream_t st) {
   if (M <= 0) return 0;
@@ -1906,14 +1922,13 @@ int launch_small_slowpath(int M, const int64_t* off, const int64_t* off2, const 
                           int64_t ldp, double* w, int* route, hipStream_t st) {
   if (M <= 0) return 0;
   const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (int rc = check_hip(hipFuncSetAttribute((const void*)small_slowpath_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
-                           "slow path LDS size"))
-      return rc;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (int rc = once.ensure([&] {
+        return check_hip(hipFuncSetAttribute((const void*)small_slowpath_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                         "slow path LDS size");
+      }))
+    return rc;
   const int grid = M < 512 ? M : 512;  // unflagged individuals cost one load each
   hipLaunchKernelGGL(small_slowpath_kernel, dim3(grid), dim3(64), dyn, st, M, off, off2, t, y, idx,
                      theta, tstride, info, Kinv, v, logdet, P, ldp, w, route);
@@ -1952,14 +1967,13 @@ static int launch_indiv_eval_t(int nsel, const int* sel, const int64_t* off, con
                                double* f, double* g, int* info, hipStream_t st) {
   // Ks + what the fragment reads of a short last tile row run past it (KL)
   const size_t dyn = ((size_t)KL<NM>::alloc + 16 * KL<NM>::TS) * sizeof(double);
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set.load()) {
-    if (int rc = check_hip(hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
-                           "indiv_eval LDS size"))
-      return rc;
-    attr_set.store(true);
-  }
+  static AttrOnce once;
+  if (int rc = once.ensure([&] {
+        return check_hip(hipFuncSetAttribute((const void*)indiv_eval_kernel<NM>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                         "indiv_eval LDS size");
+      }))
+    return rc;
   hipLaunchKernelGGL(indiv_eval_kernel<NM>, dim3(nsel), dim3(64), dyn, st, nsel, sel, off, t, y,
                      idx, theta, tstride, mean, cpack, mode, want_grad, f, g, info);
   return check_hip(hipGetLastError(), "indiv_eval");
@@ -1980,8 +1994,13 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
 }
 
 // Cap on the workgroups (= compute units) of the device-resident M-step; 0 = every compute unit.
+// Per host thread: the driver sets it around its own launch (one thread per GPU; several ranks as
+// threads of one process must not clear each other's split), the option sets the default of every
+// thread that has not set its own.
 static std::atomic<int> g_resident_max_wgs{0};
+static thread_local int t_resident_max_wgs = -1;
 void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
+void set_resident_max_workgroups_thread(int v) { t_resident_max_wgs = v; }
 // Idle wavefronts help the running ones of their workgroup (default on; same results either way).
 static std::atomic<int> g_resident_help{1};
 void set_resident_help(int v) { g_resident_help.store(v & 3); }  // bit 1: every compute unit even for few individuals (diagnostic)
@@ -2043,17 +2062,16 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
                                 int* iters, int* nfev, int* status, hipStream_t st) {
   constexpr int RW = resident_waves<NM>();
   const size_t dyn = (size_t)RW * resident_wave_doubles<NM>() * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (int rc = check_hip(hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
-                           "indiv_mstep LDS size"))
-      return rc;
-    attr_set = true;
-  }
+  static AttrOnce once;
+  if (int rc = once.ensure([&] {
+        return check_hip(hipFuncSetAttribute((const void*)indiv_mstep_kernel<NM>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                         "indiv_mstep LDS size");
+      }))
+    return rc;
   int* ticket = nullptr;
   if (int rc = resident_ticket(&ticket, st)) return rc;
-  const int cap = g_resident_max_wgs.load(std::memory_order_relaxed);
+  const int cap = t_resident_max_wgs >= 0 ? t_resident_max_wgs : g_resident_max_wgs.load(std::memory_order_relaxed);
   const int cus = device_compute_units();
   int grid = (M + RW - 1) / RW;
   if (grid > cus || (g_resident_help.load(std::memory_order_relaxed) & 2)) grid = cus;  // persistent: one workgroup fills a compute unit

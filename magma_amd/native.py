@@ -105,6 +105,11 @@ class NativeEngine:
             self.lib.magma_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p(0)
 
+    def selfcheck(self, timeout_ms=20000):
+        """magma_ctx_selfcheck: a known vector through the communicator on both streams (collective);
+        raises MagmaHipError (status 211: did not complete, 212: wrong sum)."""
+        _lib.call("magma_ctx_selfcheck", self._ctx, int(timeout_ms))
+
     def __del__(self):
         try:
             self.close()

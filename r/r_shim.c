@@ -421,6 +421,228 @@ SEXP magmahip_posterior_pred(SEXP off, SEXP t, SEXP y, SEXP extra_t, SEXP theta0
   return out;
 }
 
+/* ---- the R-named helpers on explicit arguments (kern_to_cov, kern_to_inv, dmvnorm, pred_gp) ---- */
+static int pad_vec(double **dst, const double *src, int n, int Np) { /* device copy, zero padded */
+  double *tmp = (double *)calloc(Np, sizeof(double));
+  if (!tmp) return 1;
+  memcpy(tmp, src, sizeof(double) * n);
+  int rc = up((void **)dst, tmp, sizeof(double) * Np);
+  if (!rc) rc = magma_stream_sync(NULL);
+  free(tmp);
+  return rc;
+}
+
+/* kern_to_cov / kern_to_inv, vector branch (CF:66-81, 121-138): t sorted ascending, theta3 =
+ * (theta1, theta2, sigma). invert = FALSE: K (n x n); TRUE: list(K^-1, info) -- info != 0: not
+ * positive definite, the caller takes the reference's solve() / ginv() body. Any n. */
+SEXP magmahip_kern(SEXP t, SEXP theta3, SEXP invert) {
+  const int n = LENGTH(t), Np = magma_pad(n), inv = asLogical(invert);
+  double *g = NULL, *A = NULL, *out_d = NULL, *scal = NULL;
+  void *work = NULL;
+  int hinfo = 0;
+  SEXP K = PROTECT(allocMatrix(REALSXP, n, n));
+  int rc = pad_vec(&g, REAL(t), n, Np);
+  if (!rc) rc = magma_dev_malloc((void **)&A, sizeof(double) * (size_t)Np * Np);
+  if (!rc) rc = magma_dev_malloc((void **)&out_d, sizeof(double) * (size_t)n * n);
+  if (!rc) rc = magma_kern_to_cov_grid(n, g, REAL(theta3)[0], REAL(theta3)[1], REAL(theta3)[2], A, NULL);
+  if (!rc && inv) {
+    rc = magma_dev_malloc((void **)&scal, 64);
+    if (!rc) rc = magma_dev_malloc(&work, magma_workspace_bytes(n));
+    if (!rc) rc = magma_spd_inverse(n, A, scal, (int *)(scal + 1), work, NULL);
+    if (!rc) rc = magma_memcpy_d2h(&hinfo, scal + 1, sizeof(int), NULL);
+  }
+  if (!rc) rc = magma_copy_unpad(n, A, out_d, n, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(K), out_d, sizeof(double) * (size_t)n * n, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  if (g) magma_dev_free(g);
+  if (A) magma_dev_free(A);
+  if (out_d) magma_dev_free(out_d);
+  if (scal) magma_dev_free(scal);
+  if (work) magma_dev_free(work);
+  if (rc) {
+    UNPROTECT(1);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  if (!inv) {
+    UNPROTECT(1);
+    return K;
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(out, 0, K);
+  SET_VECTOR_ELT(out, 1, ScalarInteger(hinfo));
+  UNPROTECT(2);
+  return out;
+}
+
+/* kern_to_cov / kern_to_inv, tibble branch (CF:85-112, 141-170) for individuals with n_i <= 64:
+ * off (M + 1, 0-based), t (rows sorted within an individual), theta_i 3 x M or length 3.
+ * Returns list(values: all K_i (or K_i^-1) column-major one after the other, info[M]). */
+SEXP magmahip_kern_batched(SEXP off, SEXP t, SEXP theta_i, SEXP invert) {
+  const int M = LENGTH(off) - 1, tot = LENGTH(t), inv = asLogical(invert);
+  const int stride = LENGTH(theta_i) == 3 ? 0 : 3;
+  int64_t *off64 = (int64_t *)malloc(sizeof(int64_t) * (M + 1));
+  int64_t *off2 = (int64_t *)malloc(sizeof(int64_t) * (M + 1));
+  if (!off64 || !off2) {
+    free(off64);
+    free(off2);
+    Rf_error("magmahip: out of memory");
+  }
+  int nmax = 1;
+  off2[0] = 0;
+  for (int i = 0; i <= M; ++i) off64[i] = INTEGER(off)[i];
+  for (int i = 0; i < M; ++i) {
+    const int64_t n = off64[i + 1] - off64[i];
+    if (n > nmax) nmax = (int)n;
+    off2[i + 1] = off2[i] + n * n;
+  }
+  const int64_t n2 = off2[M];
+  SEXP vals = PROTECT(allocVector(REALSXP, (R_xlen_t)n2));
+  SEXP info = PROTECT(allocVector(INTSXP, M));
+  memset(INTEGER(info), 0, sizeof(int) * M);
+  void *d_off = NULL, *d_off2 = NULL, *d_t = NULL, *d_th = NULL, *d_out = NULL, *d_ld = NULL, *d_info = NULL;
+  int rc = nmax > 64 ? 1 : 0;
+  if (rc) Rf_error("magmahip: the batched builders take at most 64 observations per individual");
+  rc = up(&d_off, off64, sizeof(int64_t) * (M + 1));
+  if (!rc) rc = up(&d_off2, off2, sizeof(int64_t) * (M + 1));
+  if (!rc) rc = up(&d_t, REAL(t), sizeof(double) * tot);
+  if (!rc) rc = up(&d_th, REAL(theta_i), sizeof(double) * LENGTH(theta_i));
+  if (!rc) rc = magma_dev_malloc(&d_out, sizeof(double) * (size_t)(n2 > 0 ? n2 : 1));
+  if (!rc && inv) rc = magma_dev_malloc(&d_ld, sizeof(double) * (M > 0 ? M : 1));
+  if (!rc && inv) rc = magma_dev_malloc(&d_info, sizeof(int) * (M > 0 ? M : 1));
+  if (!rc && !inv)
+    rc = magma_kern_to_cov_batched(M, d_off, d_off2, d_t, d_th, stride, d_out, NULL);
+  if (!rc && inv)
+    rc = magma_kern_to_inv_batched(M, nmax, d_off, d_off2, d_t, d_th, stride, d_out, d_ld, d_info, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(vals), d_out, sizeof(double) * (size_t)n2, NULL);
+  if (!rc && inv) rc = magma_memcpy_d2h(INTEGER(info), d_info, sizeof(int) * M, NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  void *fr[] = {d_off, d_off2, d_t, d_th, d_out, d_ld, d_info};
+  for (size_t i = 0; i < sizeof(fr) / sizeof(fr[0]); ++i)
+    if (fr[i]) magma_dev_free(fr[i]);
+  free(off64);
+  free(off2);
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(out, 0, vals);
+  SET_VECTOR_ELT(out, 1, info);
+  UNPROTECT(3);
+  return out;
+}
+
+/* dmvnorm(x, mu, sigma = INVERSE covariance, log = TRUE) (CF:9-34): c(value, info). */
+SEXP magmahip_dmvnorm(SEXP x, SEXP mu, SEXP inv_sigma) {
+  const int n = LENGTH(x), Np = magma_pad(n);
+  double *dx = NULL, *dmu = NULL, *dS = NULL, *tmp = NULL, hout = 0.0;
+  void *work = NULL;
+  int hinfo = 0;
+  double *mu_full = (double *)malloc(sizeof(double) * n);
+  if (!mu_full) Rf_error("magmahip: out of memory");
+  for (int i = 0; i < n; ++i) mu_full[i] = REAL(mu)[LENGTH(mu) == 1 ? 0 : i];
+  int rc = pad_vec(&dx, REAL(x), n, Np);
+  if (!rc) rc = pad_vec(&dmu, mu_full, n, Np);
+  free(mu_full);
+  if (!rc) rc = up((void **)&tmp, REAL(inv_sigma), sizeof(double) * (size_t)n * n);
+  if (!rc) rc = magma_dev_malloc((void **)&dS, sizeof(double) * (size_t)Np * Np);
+  if (!rc) rc = magma_copy_pad(n, tmp, n, dS, 0, NULL);
+  if (!rc) rc = magma_dev_malloc(&work, magma_workspace_bytes(n));
+  if (!rc) rc = magma_dmvnorm(n, dx, dmu, dS, work, &hout, &hinfo, NULL);
+  void *fr[] = {dx, dmu, dS, tmp, work};
+  for (size_t i = 0; i < sizeof(fr) / sizeof(fr[0]); ++i)
+    if (fr[i]) magma_dev_free(fr[i]);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  SEXP out = PROTECT(allocVector(REALSXP, 2));
+  REAL(out)[0] = hout;
+  REAL(out)[1] = (double)hinfo;
+  UNPROTECT(1);
+  return out;
+}
+
+/* pred_gp (MG:172-180) on explicit arguments: tn / yn / mean_obs (n <= 64, sorted by tn), ts /
+ * mean_pred (T, sorted), cov_mu N x N with idx_n / idx_t = 0-based positions of tn / ts in its
+ * dimnames (cov NULL: plain GP regression, MG:156-160), theta3 = (theta1, theta2, sigma).
+ * list(Mean, Var, info). */
+SEXP magmahip_pred_gp(SEXP tn, SEXP yn, SEXP mean_obs, SEXP idx_n, SEXP ts, SEXP mean_pred, SEXP idx_t,
+                      SEXP cov, SEXP theta3) {
+  const int n = LENGTH(tn), T = LENGTH(ts);
+  const int have_cov = !isNull(cov);
+  const int N = have_cov ? INTEGER(getAttrib(cov, R_DimSymbol))[0] : 0;
+  void *d_tn = NULL, *d_yn = NULL, *d_mo = NULL, *d_in = NULL, *d_ts = NULL, *d_mp = NULL, *d_it = NULL;
+  void *d_cov = NULL, *d_tmp = NULL, *d_th = NULL, *d_m = NULL, *d_v = NULL, *d_info = NULL;
+  SEXP pm = PROTECT(allocVector(REALSXP, T));
+  SEXP pv = PROTECT(allocVector(REALSXP, T));
+  int pinfo = 0;
+  int rc = up(&d_tn, REAL(tn), sizeof(double) * n);
+  if (!rc) rc = up(&d_yn, REAL(yn), sizeof(double) * n);
+  if (!rc) rc = up(&d_mo, REAL(mean_obs), sizeof(double) * n);
+  if (!rc) rc = up(&d_ts, REAL(ts), sizeof(double) * T);
+  if (!rc) rc = up(&d_mp, REAL(mean_pred), sizeof(double) * T);
+  if (!rc) rc = up(&d_th, REAL(theta3), sizeof(double) * 3);
+  if (!rc && have_cov) {
+    rc = up(&d_in, INTEGER(idx_n), sizeof(int) * n);
+    if (!rc) rc = up(&d_it, INTEGER(idx_t), sizeof(int) * T);
+    if (!rc) rc = up(&d_tmp, REAL(cov), sizeof(double) * (size_t)N * N);
+    if (!rc) rc = magma_dev_malloc(&d_cov, sizeof(double) * (size_t)magma_pad(N) * magma_pad(N));
+    if (!rc) rc = magma_copy_pad(N, d_tmp, N, d_cov, 0, NULL);
+  }
+  if (!rc) rc = magma_dev_malloc(&d_m, sizeof(double) * (T > 0 ? T : 1));
+  if (!rc) rc = magma_dev_malloc(&d_v, sizeof(double) * (T > 0 ? T : 1));
+  if (!rc) rc = magma_dev_malloc(&d_info, sizeof(int));
+  if (!rc) rc = magma_memset_zero(d_info, sizeof(int), NULL);
+  if (!rc)
+    rc = magma_pred_gp(n, d_tn, d_yn, d_mo, d_in, T, d_ts, d_mp, d_it, have_cov ? d_cov : NULL, N, d_th,
+                       d_m, d_v, d_info, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(pm), d_m, sizeof(double) * T, NULL);
+  if (!rc) rc = magma_memcpy_d2h(REAL(pv), d_v, sizeof(double) * T, NULL);
+  if (!rc) rc = magma_memcpy_d2h(&pinfo, d_info, sizeof(int), NULL);
+  if (!rc) rc = magma_stream_sync(NULL);
+  void *fr[] = {d_tn, d_yn, d_mo, d_in, d_ts, d_mp, d_it, d_cov, d_tmp, d_th, d_m, d_v, d_info};
+  for (size_t i = 0; i < sizeof(fr) / sizeof(fr[0]); ++i)
+    if (fr[i]) magma_dev_free(fr[i]);
+  if (rc) {
+    UNPROTECT(2);
+    Rf_error("magmahip: %s", magma_last_error());
+  }
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, pm);
+  SET_VECTOR_ELT(out, 1, pv);
+  SET_VECTOR_ELT(out, 2, ScalarInteger(pinfo)); /* != 0: use the reference's solve() / ginv() body */
+  UNPROTECT(3);
+  return out;
+}
+
+/* e_step / posterior_mu body through the native driver (any n_i: individuals with more than 64
+ * observations take the dense route inside the library): list(mean, cov, info). */
+SEXP magmahip_e_step_native(SEXP hx, SEXP theta0, SEXP pen, SEXP theta_i, SEXP m0) {
+  native *h = get_native(hx);
+  int info = 0;
+  int rc = magma_e_step(h->ctx, h->ds, REAL(theta0), REAL(theta_i), LENGTH(theta_i) == 3 ? 0 : 3,
+                        REAL(pen)[0], REAL(m0), LENGTH(m0), &info, NULL);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  SEXP par = PROTECT(native_param(h));
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, VECTOR_ELT(par, 0));
+  SET_VECTOR_ELT(out, 1, VECTOR_ELT(par, 1));
+  SET_VECTOR_ELT(out, 2, ScalarInteger(info));
+  UNPROTECT(2);
+  return out;
+}
+
+/* logL_monitoring (CF:236-264) through the native driver against a hyper-posterior given by the
+ * caller (any n_i). */
+SEXP magmahip_logl_monitoring_native(SEXP hx, SEXP mean, SEXP cov, SEXP m0, SEXP theta0, SEXP theta_i) {
+  native *h = get_native(hx);
+  double out = 0.0;
+  int rc = magma_set_m0(h->ctx, h->ds, REAL(m0), LENGTH(m0));
+  if (!rc) rc = magma_set_mean_cov(h->ctx, h->ds, REAL(mean), REAL(cov), h->N);
+  if (!rc)
+    rc = magma_logl_monitoring(h->ctx, h->ds, REAL(theta0), REAL(theta_i), LENGTH(theta_i) == 3 ? 0 : 3, &out);
+  if (rc) Rf_error("magmahip: %s", magma_last_error());
+  return ScalarReal(out);
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"magmahip_dataset", (DL_FUNC)&magmahip_dataset, 4},
     {"magmahip_training", (DL_FUNC)&magmahip_training, 5},
@@ -433,6 +655,12 @@ static const R_CallMethodDef call_methods[] = {
     {"magmahip_indiv_eval", (DL_FUNC)&magmahip_indiv_eval, 4},
     {"magmahip_indiv_mstep", (DL_FUNC)&magmahip_indiv_mstep, 3},
     {"magmahip_theta0_eval", (DL_FUNC)&magmahip_theta0_eval, 5},
+    {"magmahip_kern", (DL_FUNC)&magmahip_kern, 3},
+    {"magmahip_kern_batched", (DL_FUNC)&magmahip_kern_batched, 4},
+    {"magmahip_dmvnorm", (DL_FUNC)&magmahip_dmvnorm, 3},
+    {"magmahip_pred_gp", (DL_FUNC)&magmahip_pred_gp, 9},
+    {"magmahip_e_step_native", (DL_FUNC)&magmahip_e_step_native, 5},
+    {"magmahip_logl_monitoring_native", (DL_FUNC)&magmahip_logl_monitoring_native, 6},
     {NULL, NULL, 0}};
 
 void R_init_magmahip(DllInfo *dll) {
