@@ -77,8 +77,11 @@ int magma_prof_reset(void);
  * is used up to this many 64-row blocks. Driver switches (default 1): "prefactor" (the M-step's
  * first K_0 inverse started next to the E-step's), "prefetch" (the next E-step's sums started
  * under the monitoring call), "cov_factor" (theta_0 gradient through the E-step's triangular
- * factor of cov; one rank). Results do not depend on any of them except "dag_walker" and
- * "cov_factor" (summation order: last bits). */
+ * factor of cov; one rank, or every rank with "theta0_shard" 0), "theta0_shard" (several ranks: the
+ * two N^3 products of the theta_0 gradient split by block rows and two sums all-reduced per
+ * evaluation; 0 = every rank forms the whole gradient, nothing exchanged per evaluation). Results
+ * do not depend on any of them except "dag_walker", "cov_factor" and "theta0_shard" (summation
+ * order: last bits). */
 int magma_set_option(const char* name, long value);
 int magma_prof_get(int id, int* h_count, double* h_total_ms);
 

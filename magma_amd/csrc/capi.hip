@@ -600,6 +600,10 @@ int magma_set_option(const char* name, long value) {
     set_prefactor(value != 0);
     return 0;
   }
+  if (std::string(name) == "theta0_shard") {  // several ranks: theta_0 gradient products split by block rows
+    set_theta0_shard(value != 0);
+    return 0;
+  }
   if (std::string(name) == "cov_factor") {  // theta_0 gradient through the E-step's factor of cov
     set_covfac(value != 0);
     return 0;

@@ -69,6 +69,10 @@ void set_dedup(bool on);
 bool prefetch_enabled();
 void set_prefetch(bool on);
 bool covfac_enabled();
+// several ranks: split the two N^3 products of the theta_0 gradient by block rows (default), or let
+// every rank form the whole gradient (no exchange per evaluation; cov_factor then applies)
+bool theta0_shard_enabled();
+void set_theta0_shard(bool on);
 void set_covfac(bool on);
 bool prefactor_enabled();
 void set_prefactor(bool on);

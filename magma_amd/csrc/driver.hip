@@ -971,7 +971,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   if (info == 0 && d->cpack_early)
     if ((rc = ensure_cpack(d, st))) return rc;
   d->covfac_ok = false;
-  if (info == 0 && !c->has_comm() && d->covfac.p && covfac_enabled()) {
+  if (info == 0 && (!c->has_comm() || !theta0_shard_enabled()) && d->covfac.p && covfac_enabled()) {
     if ((rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
     d->covfac_ok = true;
   }
@@ -1042,7 +1042,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     rc0 = theta0_mstep_impl(d->N, d->grid.as<double>(), h_theta0, pen, d->mean.as<double>(),
                             d->m0.as<double>(), d->P.as<double>(), o.m, o.factr, o.pgtol, o.maxit,
                             d->work0.p, th0_new, nullptr, nullptr, nullptr, &nfev0, nullptr, c->side,
-                            c->has_comm() ? &sh : nullptr,
+                            (c->has_comm() && theta0_shard_enabled()) ? &sh : nullptr,
                             d->covfac_ok ? d->covfac.as<double>() : nullptr, pre0);
     if (rc0) err0 = magma_last_error();
   };

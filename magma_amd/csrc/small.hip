@@ -92,167 +92,6 @@ __global__ __launch_bounds__(256) void se_cov_batched_kernel(
   }
 }
 
-// ------------------------------------------------------------------ K(theta)^-1 into LDS
-// Build the SE covariance of one individual in accumulator layout (identity padded to NMAX),
-// invert it with the blocked MFMA sweep (mfma_sweep.h; scaled to a unit diagonal first) and
-// leave K^-1 in LDS as Ks[r * NMAX + c] (symmetric). Ks: NMAX * NMAX + 16 doubles, its head
-// doubles as the sweep's transposition buffer. Ends with a wave_sync().
-template <int NMAX>
-__device__ __forceinline__ void se_inverse_to_lds(int lane, int n, const SEParams& p,
-                                                  const double* tbuf, double* Ks, double& logdet,
-                                                  int& info) {
-  constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4, LD = NMAX;
-  static_assert(NMAX % 4 == 0, "NMAX must be a multiple of 4");
-  const int l = lane & 15, g = lane >> 4;
-  const double sc = 1.0 / (p.eth1 + p.sig2);
-  v4d A[NT][NT];
-  double tcol[NT];
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt) tcol[jt] = tbuf[16 * jt + l];
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (16 * it + 4 * v >= NMAX) {
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) A[it][jt][v] = 0.0;
-        continue;
-      }
-      const int r = 16 * it + 4 * v + g;
-      const double trow = tbuf[r];
-#pragma unroll
-      for (int jt = 0; jt <= it; ++jt) {  // tiles above the diagonal: by symmetry, see eval_factor
-        const int c = 16 * jt + l;
-        const double d = trow - tcol[jt];
-        double kv = exp(p.th1 - p.h * d * d) * sc;
-        kv = (r == c) ? 1.0 : kv;
-        A[it][jt][v] = (r < n && c < n) ? kv : ((r == c) ? 1.0 : 0.0);
-        if (jt < it) Ks[c * LD + r] = A[it][jt][v];
-        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled exp() bodies sequential
-      }
-    }
-  }
-  if constexpr (NT > 1) {
-    wave_sync();
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (16 * it + 4 * v >= NMAX) continue;
-        const int r = 16 * it + 4 * v + g;
-#pragma unroll
-        for (int jt = it + 1; jt < NT; ++jt) {
-          const int c = 16 * jt + l;
-          A[it][jt][v] = (16 * jt + 15 < NMAX || c < NMAX) ? Ks[r * LD + c] : 0.0;
-        }
-      }
-    wave_sync();  // every load is issued before the sweep reuses the head of Ks
-  }
-  double pm = 1.0;
-  int pe = 0;
-  info = 0;
-  mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
-  logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
-#pragma unroll
-  for (int it = 0; it < NT; ++it)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (16 * it + 4 * v >= NMAX) continue;
-      const int r = 16 * it + 4 * v + g;
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const int c = 16 * jt + l;
-        if (16 * jt + 15 < NMAX || c < NMAX) Ks[r * LD + c] = -sc * A[it][jt][v];
-      }
-    }
-  wave_sync();
-}
-
-// ------------------------------------------------------------------ K1+K3: inverse to HBM
-// With y / v given (the deterministic E-step): v_i = K_i^-1 y_i as well; a flagged (not positive
-// definite) individual gets zeros in both here and its solve() / ginv() answer from
-// small_slowpath_kernel, launched right behind this kernel.
-template <int NMAX>
-__global__ __launch_bounds__(64) void se_inv_batched_kernel(
-    int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
-    const double* __restrict__ t, const double* __restrict__ theta, int tstride,
-    double* __restrict__ out, double* __restrict__ logdet_out, int* __restrict__ info_out,
-    const double* __restrict__ y, double* __restrict__ v) {
-  __shared__ double tbuf[64];
-  __shared__ double ybuf[64];
-  extern __shared__ __attribute__((aligned(16))) double Ks[];
-  const int i = blockIdx.x, lane = threadIdx.x;
-  const int64_t o = off[i];
-  const int n = (int)(off[i + 1] - o);
-  const double* th = theta + (int64_t)i * tstride;
-  const SEParams p = se_params(th[0], th[1], th[2]);
-  tbuf[lane] = (lane < n) ? t[o + lane] : 0.0;
-  ybuf[lane] = (v != nullptr && lane < n) ? y[o + lane] : 0.0;
-  __syncthreads();
-  double logdet;
-  int info;
-  se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
-  double* Kinv = out + off2[i];
-  const bool zero = (v != nullptr && info != 0);
-  if (lane < n) {
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c)
-      if (c < n) {
-        const double k = zero ? 0.0 : Ks[c * NMAX + lane];
-        Kinv[(int64_t)c * n + lane] = k;
-        s = fma(k, ybuf[c], s);
-      }
-    if (v != nullptr) v[o + lane] = s;
-  }
-  if (lane == 0) {
-    logdet_out[i] = logdet;
-    info_out[i] = info;
-  }
-}
-
-// ------------------------------------------------------------------ E-step scatter
-// P[idx_a, idx_b] += K_i^-1[a, b] (lower triangle only: idx ascending within an individual),
-// w[idx_a] += (K_i^-1 y_i)[a]. FP64 hardware atomics into the L2-resident N x N partial
-// precision; K_i and K_i^-1 never touch HBM.
-template <int NMAX>
-__global__ __launch_bounds__(64) void estep_scatter_kernel(
-    int M, const int64_t* __restrict__ off, const double* __restrict__ t,
-    const double* __restrict__ y, const int* __restrict__ idx,
-    const double* __restrict__ theta, int tstride, double* __restrict__ P, int64_t ldp,
-    double* __restrict__ w, int* __restrict__ info_out) {
-  __shared__ double tbuf[64];
-  __shared__ double ybuf[64];
-  __shared__ int ibuf[64];
-  extern __shared__ __attribute__((aligned(16))) double Ks[];
-  const int i = blockIdx.x, lane = threadIdx.x;
-  const int64_t o = off[i];
-  const int n = (int)(off[i + 1] - o);
-  const double* th = theta + (int64_t)i * tstride;
-  const SEParams p = se_params(th[0], th[1], th[2]);
-  const bool rv = lane < n;
-  const int ir = rv ? idx[o + lane] : 0;
-  tbuf[lane] = rv ? t[o + lane] : 0.0;
-  ybuf[lane] = rv ? y[o + lane] : 0.0;
-  ibuf[lane] = ir;
-  __syncthreads();
-  double logdet;
-  int info;
-  se_inverse_to_lds<NMAX>(lane, n, p, tbuf, Ks, logdet, info);
-  if (lane == 0) info_out[i] = info;
-  if (info != 0) return;  // flagged: small_slowpath_kernel adds its solve() / ginv() answer
-  if (rv) {  // lane r owns row r = column r of K^-1: Ks[c * NMAX + r] is conflict free
-    double wi = 0.0;
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) wi = fma(Ks[c * NMAX + lane], ybuf[c], wi);
-    unsafeAtomicAdd(&w[ir], wi);
-#pragma unroll
-    for (int c = 0; c < NMAX; ++c) {
-      if (c <= lane) unsafeAtomicAdd(&P[(int64_t)ibuf[c] * ldp + ir], Ks[c * NMAX + lane]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------ slow path: solve() / ginv()
 // `tryCatch(solve(mat), error = function(e) MASS::ginv(mat))` (CF:133,161; MG:173) for the K_i the
 // Cholesky-type sweep flagged (info != 0): numerically singular or indefinite by rounding
@@ -1209,6 +1048,117 @@ __global__ __launch_bounds__(64, MAGMA_INDIV_WAVES * indiv_eval_waves<NMAX>()) v
   }
 }
 
+// ------------------------------------------------------------------ K1+K3: inverse to HBM
+// Row `lane` of K^-1 from the lower-tile LDS image (KL): element (lane, c) for compile-time c sits
+// in this lane's own tile row when c's tile is left of / on the diagonal tile, else in tile row
+// c >> 4 by symmetry (see eval_alpha).
+template <int NMAX>
+struct KinvRow {
+  int rt, rl, rsz, base_r;
+  __device__ __forceinline__ explicit KinvRow(int lane) {
+    using L = KL<NMAX>;
+    const int lr = lane < NMAX ? lane : 0;
+    rt = lr >> 4;
+    rl = lr & 15;
+    rsz = ((rt == L::NT - 1) ? L::rows(L::NT - 1) : 16) * L::TS;
+    base_r = 16 * L::TS * (rt * (rt + 1) / 2) + rl * L::TS;
+  }
+  __device__ __forceinline__ double at(const double* Ks, int c) const {
+    using L = KL<NMAX>;
+    const int ct = c >> 4, cl = c & 15;
+    const int a_row = base_r + ct * rsz + cl;
+    const int a_col = L::tb(ct, 0) + rt * (L::rows(ct) * L::TS) + cl * L::TS + rl;
+    return Ks[rt >= ct ? a_row : a_col];
+  }
+};
+
+// With y / v given (the deterministic E-step): v_i = K_i^-1 y_i as well; a flagged (not positive
+// definite) individual gets zeros in both here and its solve() / ginv() answer from
+// small_slowpath_kernel, launched right behind this kernel. Same factorisation as the M-step's
+// evaluations (eval_factor: lower tiles, two wavefronts per SIMD up to 52 rows).
+template <int NMAX>
+__global__ __launch_bounds__(64, indiv_eval_waves<NMAX>()) void se_inv_batched_kernel(
+    int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
+    const double* __restrict__ t, const double* __restrict__ theta, int tstride,
+    double* __restrict__ out, double* __restrict__ logdet_out, int* __restrict__ info_out,
+    const double* __restrict__ y, double* __restrict__ v) {
+  __shared__ double tbuf[64];
+  __shared__ double ybuf[64];
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int64_t o = off[i];
+  const int n = (int)(off[i + 1] - o);
+  const double* th = theta + (int64_t)i * tstride;
+  const SEParams p = se_params(th[0], th[1], th[2]);
+  tbuf[lane] = (lane < n) ? t[o + lane] : 0.0;
+  ybuf[lane] = (v != nullptr && lane < n) ? y[o + lane] : 0.0;
+  __syncthreads();
+  double logdet;
+  int info;
+  eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, nullptr, 0, logdet, info);
+  double* Kinv = out + off2[i];
+  const bool zero = (v != nullptr && info != 0);
+  const KinvRow<NMAX> row(lane);
+  if (lane < n) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c)
+      if (c < n) {
+        const double k = zero ? 0.0 : row.at(Ks, c);
+        Kinv[(int64_t)c * n + lane] = k;
+        s = fma(k, ybuf[c], s);
+      }
+    if (v != nullptr) v[o + lane] = s;
+  }
+  if (lane == 0) {
+    logdet_out[i] = logdet;
+    info_out[i] = info;
+  }
+}
+
+// ------------------------------------------------------------------ E-step scatter
+// P[idx_a, idx_b] += K_i^-1[a, b] (lower triangle only: idx ascending within an individual),
+// w[idx_a] += (K_i^-1 y_i)[a]. FP64 hardware atomics into the L2-resident N x N partial
+// precision; K_i and K_i^-1 never touch HBM.
+template <int NMAX>
+__global__ __launch_bounds__(64, indiv_eval_waves<NMAX>()) void estep_scatter_kernel(
+    int M, const int64_t* __restrict__ off, const double* __restrict__ t,
+    const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ theta, int tstride, double* __restrict__ P, int64_t ldp,
+    double* __restrict__ w, int* __restrict__ info_out) {
+  __shared__ double tbuf[64];
+  __shared__ double ybuf[64];
+  __shared__ int ibuf[64];
+  extern __shared__ __attribute__((aligned(16))) double Ks[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int64_t o = off[i];
+  const int n = (int)(off[i + 1] - o);
+  const double* th = theta + (int64_t)i * tstride;
+  const SEParams p = se_params(th[0], th[1], th[2]);
+  const bool rv = lane < n;
+  const int ir = rv ? idx[o + lane] : 0;
+  tbuf[lane] = rv ? t[o + lane] : 0.0;
+  ybuf[lane] = rv ? y[o + lane] : 0.0;
+  ibuf[lane] = ir;
+  __syncthreads();
+  double logdet;
+  int info;
+  eval_factor<NMAX>(lane, n, i, p, tbuf, Ks, nullptr, 0, logdet, info);
+  if (lane == 0) info_out[i] = info;
+  if (info != 0) return;  // flagged: small_slowpath_kernel adds its solve() / ginv() answer
+  const KinvRow<NMAX> row(lane);
+  if (rv) {
+    double wi = 0.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) wi = fma(row.at(Ks, c), ybuf[c], wi);
+    unsafeAtomicAdd(&w[ir], wi);
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+      if (c <= lane) unsafeAtomicAdd(&P[(int64_t)ibuf[c] * ldp + ir], row.at(Ks, c));
+    }
+  }
+}
+
 // ------------------------------------------------------------------ device-resident M-step
 // m_step's individual part (CF:419-432: one optim() per individual) without leaving the GPU:
 // the wavefront that evaluates an individual also runs its L-BFGS-B (lbfgsb_core.h, the very
@@ -1897,8 +1847,9 @@ int launch_se_inv_batched(int M, int nmax, const int64_t* off, const int64_t* of
                           double* logdet, int* info, const double* y, double* v, hipStream_t st) {
   if (M <= 0) return 0;
 #define CALL(NM)                                                                              \
-  hipLaunchKernelGGL(se_inv_batched_kernel<NM>, dim3(M), dim3(64), (NM * NM + 16) * sizeof(double), \
-                     st, M, off, off2, t, theta, tstride, out, logdet, info, y, v)
+  hipLaunchKernelGGL(se_inv_batched_kernel<NM>, dim3(M), dim3(64),                              \
+                     (KL<NM>::alloc + 16 * KL<NM>::TS) * sizeof(double), st, M, off, off2, t, theta, \
+                     tstride, out, logdet, info, y, v)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "se_inv_batched");
@@ -1909,8 +1860,9 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
                          int64_t ldp, double* w, int* info, hipStream_t st) {
   if (M <= 0) return 0;
 #define CALL(NM)                                                                             \
-  hipLaunchKernelGGL(estep_scatter_kernel<NM>, dim3(M), dim3(64), (NM * NM + 16) * sizeof(double), \
-                     st, M, off, t, y, idx, theta, tstride, P, ldp, w, info)
+  hipLaunchKernelGGL(estep_scatter_kernel<NM>, dim3(M), dim3(64),                             \
+                     (KL<NM>::alloc + 16 * KL<NM>::TS) * sizeof(double), st, M, off, t, y, idx,    \
+                     theta, tstride, P, ldp, w, info)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
   return check_hip(hipGetLastError(), "estep_scatter");
@@ -2105,6 +2057,9 @@ static std::atomic<bool> g_prefetch{true};
 bool prefetch_enabled() { return g_prefetch.load(); }
 void set_prefetch(bool on) { g_prefetch.store(on); }
 static std::atomic<bool> g_covfac{true};
+static std::atomic<bool> g_theta0_shard{true};
+bool theta0_shard_enabled() { return g_theta0_shard.load(); }
+void set_theta0_shard(bool on) { g_theta0_shard.store(on); }
 bool covfac_enabled() { return g_covfac.load(); }
 void set_covfac(bool on) { g_covfac.store(on); }
 static std::atomic<bool> g_prefactor{true};

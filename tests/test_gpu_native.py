@@ -223,6 +223,35 @@ def test_native_ranks_as_threads_equal_one_rank(m, world, N):
     one.close()
 
 
+def test_replicated_theta0_with_several_ranks_equals_one_rank(m):
+    """Option "theta0_shard" = 0: every rank forms the whole theta_0 gradient (through the factor of
+    cov, nothing exchanged per evaluation) while the individuals stay sharded. Two and four ranks
+    as threads: theta_0 is then the one-rank result to the rounding of the all-reduced precision,
+    and bit-identical on all ranks."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(203, 30, 450, seed=31)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    th0, thi = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (203, 1))
+
+    def job(eng):
+        return eng.em_iteration(th0, thi, 0.3, False)
+    one = NativeEngine(ds)
+    ref = job(one)
+    one.close()
+    try:
+        _lib.call("magma_set_option", b"theta0_shard", 0)
+        for world in (2, 4):
+            res = _run_ranks(ds, world, job)
+            for r in res:
+                assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and r[2:] == res[0][2:]
+            assert np.abs(res[0][0] - ref[0]).max() < 1e-7, (world, res[0][0], ref[0])
+            assert abs(res[0][2] - ref[2]) < 1e-11 * abs(ref[2]) and abs(res[0][3] - ref[3]) < 1e-6 * abs(ref[3])
+    finally:
+        _lib.call("magma_set_option", b"theta0_shard", 1)
+
+
 def test_sharded_theta0_gradient_equals_unsharded(m):
     """One theta_0 evaluation with its products split 1-, 2-, 5-ways agrees to summation order:
     checked through the M-step's first iterate with maxit = 1 (the optimiser's first step is a
