@@ -273,6 +273,7 @@ typedef struct {
   int64_t indiv_evals;  /* per-individual objective + gradient evaluations on this rank */
   int64_t common_evals; /* evaluations of the common-HP objective */
   int64_t flagged;      /* individuals whose K_i was not positive definite in an E-step */
+  int64_t slow_resolved; /* individual M-step problems solved again through solve() / ginv() */
 } magma_em_stats;
 
 int magma_comm_unique_id(void* h_out128);

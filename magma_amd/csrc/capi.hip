@@ -496,13 +496,14 @@ int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double
 namespace {
 struct MstepStage {
   size_t cap = 0;
-  int* sel = nullptr;
+  int *sel = nullptr, *sel2 = nullptr;
   double *theta = nullptr, *f = nullptr, *g = nullptr;
   int ensure(size_t M) {
     if (M <= cap) return 0;
     release();
     const size_t c = M + M / 2 + 64;
     if (hipHostMalloc((void**)&sel, c * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&sel2, c * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&theta, 3 * c * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void**)&f, c * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void**)&g, 3 * c * sizeof(double)) != hipSuccess) {
@@ -514,10 +515,11 @@ struct MstepStage {
   }
   void release() {
     if (sel) (void)hipHostFree(sel);
+    if (sel2) (void)hipHostFree(sel2);
     if (theta) (void)hipHostFree(theta);
     if (f) (void)hipHostFree(f);
     if (g) (void)hipHostFree(g);
-    sel = nullptr;
+    sel = sel2 = nullptr;
     theta = f = g = nullptr;
     cap = 0;
   }
@@ -525,20 +527,23 @@ struct MstepStage {
 thread_local MstepStage g_stage;
 }  // namespace
 
-int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const double* t,
-                      const double* y, const int* idx, const double* mean, const double* cpack,
-                      const double* h_theta0, int m, double factr, double pgtol, int maxit,
-                      double* d_theta, int* d_sel, double* d_f, double* d_g, int* d_info,
-                      double* h_theta_out, double* h_f_out, double* h_f_x0, int* h_iters,
-                      int* h_nfev, int* h_status, int* h_rounds, int64_t* h_nevals, void* stream) {
-  if (int rc = check_small(M, nmax)) return rc;
-  if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
+}  // extern "C"
+namespace magma {
+// The lock-step route over all M individuals (subset == nullptr) or over the nsub listed ones
+// (results then by position in the list; h_theta0 holds 3 doubles per listed individual).
+int indiv_mstep_lockstep(int mode, int M, int nmax, const int64_t* off, const double* t,
+                         const double* y, const int* idx, const double* mean, const double* cpack,
+                         const double* h_theta0, const int* subset, int nsub, int m, double factr,
+                         double pgtol, int maxit, double* d_theta, int* d_sel, double* d_f,
+                         double* d_g, int* d_info, double* h_theta_out, double* h_f_out,
+                         double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, int* h_rounds,
+                         int64_t* h_nevals, hipStream_t st) {
   if (h_rounds) *h_rounds = 0;
   if (h_nevals) *h_nevals = 0;
-  if (M == 0) return 0;
-  if (int rc = g_stage.ensure((size_t)M)) return rc;
-  hipStream_t st = S(stream);
-  magma_lbfgsb* opt = magma_lbfgsb_create(M, 3, h_theta0, m, factr, pgtol, maxit);
+  const int B = subset ? nsub : M;
+  if (B <= 0) return 0;
+  if (int rc = g_stage.ensure((size_t)B)) return rc;
+  magma_lbfgsb* opt = magma_lbfgsb_create(B, 3, h_theta0, m, factr, pgtol, maxit);
   if (!opt) return fail(2, "magma_indiv_mstep: bad optimiser parameters");
   int rc = 0, rounds = 0;
   int64_t nevals = 0;
@@ -546,9 +551,14 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
     int na = 0;
     magma_lbfgsb_ask_compact(opt, g_stage.sel, g_stage.theta, &na);
     if (na == 0) break;
-    const bool all = (na == M);
+    const bool all = (subset == nullptr && na == M);
+    const int* hsel = g_stage.sel;
+    if (subset) {  // problem k of the optimiser is individual subset[k]
+      for (int k = 0; k < na; ++k) g_stage.sel2[k] = subset[g_stage.sel[k]];
+      hsel = g_stage.sel2;
+    }
     if (!all &&
-        (rc = check_hip(hipMemcpyAsync(d_sel, g_stage.sel, sizeof(int) * na, hipMemcpyHostToDevice, st),
+        (rc = check_hip(hipMemcpyAsync(d_sel, hsel, sizeof(int) * na, hipMemcpyHostToDevice, st),
                         "mstep sel h2d")))
       break;
     if ((rc = check_hip(hipMemcpyAsync(d_theta, g_stage.theta, sizeof(double) * 3 * na,
@@ -578,6 +588,21 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
   if (h_rounds) *h_rounds = rounds;
   if (h_nevals) *h_nevals = nevals;
   return rc;
+}
+}  // namespace magma
+extern "C" {
+
+int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const double* t,
+                      const double* y, const int* idx, const double* mean, const double* cpack,
+                      const double* h_theta0, int m, double factr, double pgtol, int maxit,
+                      double* d_theta, int* d_sel, double* d_f, double* d_g, int* d_info,
+                      double* h_theta_out, double* h_f_out, double* h_f_x0, int* h_iters,
+                      int* h_nfev, int* h_status, int* h_rounds, int64_t* h_nevals, void* stream) {
+  if (int rc = check_small(M, nmax)) return rc;
+  if (mode != 0 && mode != 1) return fail(2, "mode must be 0 (logL_GP_mod) or 1 (logL_GP)");
+  return indiv_mstep_lockstep(mode, M, nmax, off, t, y, idx, mean, cpack, h_theta0, nullptr, 0, m, factr,
+                              pgtol, maxit, d_theta, d_sel, d_f, d_g, d_info, h_theta_out, h_f_out,
+                              h_f_x0, h_iters, h_nfev, h_status, h_rounds, h_nevals, S(stream));
 }
 
 int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,

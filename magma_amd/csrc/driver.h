@@ -54,6 +54,17 @@ int dag_diag(int N, void* work, int* h_two);
 int indiv_dense_eval_impl(int n, const double* grid, const double* th3, const double* yv,
                           const double* mvec, const double* C, int want_grad, void* work,
                           double* h_out4, int* h_info, hipStream_t st);
+// The lock-step route of the individual problems (magma_indiv_mstep) over all M individuals
+// (subset == nullptr) or over the nsub listed ones: results by position in the list, h_theta0 with
+// 3 doubles per listed individual. Every evaluation goes through launch_indiv_eval, i.e. flagged
+// covariances are answered by solve() / ginv(). d_* : device staging for max(M, nsub) problems.
+int indiv_mstep_lockstep(int mode, int M, int nmax, const int64_t* off, const double* t,
+                         const double* y, const int* idx, const double* mean, const double* cpack,
+                         const double* h_theta0, const int* subset, int nsub, int m, double factr,
+                         double pgtol, int maxit, double* d_theta, int* d_sel, double* d_f,
+                         double* d_g, int* d_info, double* h_theta_out, double* h_f_out,
+                         double* h_f_x0, int* h_iters, int* h_nfev, int* h_status, int* h_rounds,
+                         int64_t* h_nevals, hipStream_t st);
 int launch_trace(int N, int64_t ld, const double* A, double* out, hipStream_t st);
 int launch_gather_block(int n, int np, const int* idx, const double* cov, int64_t ldc,
                         const double* mean, double* C, double* m, hipStream_t st);

@@ -114,6 +114,12 @@ struct DevBuf {
     bytes = b;
     return check_hip(hipMalloc(&p, b ? b : 8), "hipMalloc");
   }
+  int ensure(size_t b) {  // grow only
+    if (p && b <= bytes) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    return alloc(b);
+  }
   ~DevBuf() { if (p) (void)hipFree(p); }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
@@ -149,7 +155,7 @@ struct magma_dataset {
   DevBuf theta, f, g, info, sel, fsum;
   DevBuf P, w, mean, m0, work, cpack, pack;
   // resident M-step results: x (3 M), f (M), f(x0) (M) doubles, evaluation counts (M ints)
-  DevBuf rres, rit, rst, gath;
+  DevBuf rres, rit, rst, gath, redo_theta;
   void* h_rres = nullptr;  // pinned mirror
   DevBuf plist;  // lower tiles of the theta_0 gradient owned by this rank
   int nplist = 0;
@@ -191,7 +197,7 @@ struct magma_dataset {
   DevBuf order;
   // by-products of the last E-step / M-step (logL_monitoring shortcuts, MG:54,60)
   double last_f0 = 0.0, last_sum_fi = 0.0, last_sum_fi_new = 0.0;
-  magma_em_stats stats = {0, 0, 0, 0, 0};
+  magma_em_stats stats = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -873,7 +879,7 @@ int magma_get_stats(const magma_dataset* d, magma_em_stats* out, int reset) {
     if (int rc = count_flagged(dd, dd->ctx->main)) return rc;
   }
   *out = d->stats;
-  if (reset) const_cast<magma_dataset*>(d)->stats = magma_em_stats{0, 0, 0, 0, 0};
+  if (reset) const_cast<magma_dataset*>(d)->stats = magma_em_stats{0, 0, 0, 0, 0, 0};
   return 0;
 }
 
@@ -1120,7 +1126,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                              d->rres.as<double>() + 3 * M, d->rres.as<double>() + 4 * M,
                                              d->rit.as<int>(),
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M),
-                                             d->rst.as<int>(), st)))
+                                             reinterpret_cast<int*>(d->rres.as<double>() + 5 * M) + M, st)))
           break;
         // x, f, f(x0) and the evaluation counts sit in one block: one copy into pinned memory
         if (!d->h_rres &&
@@ -1135,6 +1141,38 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
           std::copy(hr + 4 * M, hr + 5 * M, hfx0.begin());
           const int* hn = reinterpret_cast<const int*>(hr + 5 * M);
           std::copy(hn, hn + M, hnf.begin());
+          // status 6: one of the problem's covariances was not positive definite for the sweep.
+          // The reference evaluates those through solve() / ginv() (CF:133): such problems are
+          // solved again, from their start, by the lock-step route, whose evaluations do that.
+          std::vector<int> redo;
+          for (int64_t i = 0; i < M; ++i)
+            if (hn[M + i] == 6) redo.push_back((int)i);
+          if (!redo.empty()) {
+            const int nr = (int)redo.size();
+            std::vector<double> x0((size_t)3 * nr), xr((size_t)3 * nr), fr((size_t)nr), f0r((size_t)nr);
+            std::vector<int> nfr((size_t)nr);
+            for (int k = 0; k < nr; ++k) {
+              const double* row = theta_row(d, h_theta_i, 3, d->small_row[(size_t)redo[(size_t)k]]);
+              std::copy(row, row + 3, x0.begin() + 3 * k);
+            }
+            if ((rc = d->redo_theta.ensure(sizeof(double) * 3 * (size_t)nr))) break;
+            if ((rc = indiv_mstep_lockstep(0, (int)M, d->nmax, d->off.as<int64_t>(), d->t.as<double>(),
+                                           d->y.as<double>(), d->idx.as<int>(), d->mean.as<double>(),
+                                           d->cpack.as<double>(), x0.data(), redo.data(), nr, o.m, o.factr,
+                                           o.pgtol, o.maxit, d->redo_theta.as<double>(), d->sel.as<int>(),
+                                           d->f.as<double>(), d->g.as<double>(), d->info.as<int>(),
+                                           xr.data(), fr.data(), f0r.data(), nullptr, nfr.data(), nullptr,
+                                           nullptr, nullptr, st)))
+              break;
+            for (int k = 0; k < nr; ++k) {
+              const size_t i = (size_t)redo[(size_t)k];
+              std::copy(xr.begin() + 3 * k, xr.begin() + 3 * k + 3, hx.begin() + 3 * i);
+              hf[i] = fr[(size_t)k];
+              hfx0[i] = f0r[(size_t)k];
+              hnf[i] += nfr[(size_t)k];
+            }
+            d->stats.slow_resolved += nr;
+          }
         }
         HT("m: resident (launch + d2h sync)");
         {  // next call's order: by evaluation count, descending, stable (counting sort)

@@ -110,7 +110,227 @@ __global__ __launch_bounds__(256) void se_cov_batched_kernel(
 // P / w with atomics (P != null). logdet_out (optional): log|det K| of the LU, NaN after ginv().
 // route_out[i]: 1 = solve() answered, 2 = ginv().
 constexpr int SP_LD = 65;
-constexpr int SP_LDS_DOUBLES = 2 * 64 * SP_LD + 5 * 64;
+constexpr int SP_LDS_DOUBLES = 2 * 64 * SP_LD + 8 * 64;
+
+struct SlowInv {
+  double* R;      // the answer: solve()'s inverse or ginv()'s pseudo-inverse
+  double* F;      // the other 64 x SP_LD matrix, free for the caller
+  int route;      // 1 = solve() answered, 2 = ginv()
+  double logdet;  // log|det| of the LU (route 1), NaN after ginv()
+};
+
+// build(): lane r writes row r of the matrix into A and returns sum_c |A[r][c]| (= the 1-norm of
+// column r by symmetry). Ends with a workgroup barrier; the workgroup is one wavefront.
+template <class Build>
+__device__ __forceinline__ SlowInv slow_solve_or_ginv(int lane, int n, double* A, double* B,
+                                                      double* cbuf, double* sbuf, double* lam,
+                                                      int* pq, Build&& build) {
+  const double eps = 2.220446049250313e-16;
+  double n1 = build();
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) n1 = fmax(n1, __shfl_xor(n1, s));
+  if (lane < n)
+    for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
+  __syncthreads();
+  // ---- 1. solve(): Gauss-Jordan, partial pivoting
+  bool singular = false;
+  double logdet = 0.0;
+  for (int k = 0; k < n; ++k) {
+    double best = (lane >= k && lane < n) ? fabs(A[lane * SP_LD + k]) : -1.0;
+    int bi = lane;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const double ob = __shfl_xor(best, s);
+      const int oi = __shfl_xor(bi, s);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (!(best > 0.0) || !(best < 1.7e308)) {
+      singular = true;
+      break;
+    }
+    if (lane < n && bi != k) {  // swap rows k and bi (lane = column)
+      const double a = A[k * SP_LD + lane], b = A[bi * SP_LD + lane];
+      A[k * SP_LD + lane] = b;
+      A[bi * SP_LD + lane] = a;
+      const double c = B[k * SP_LD + lane], d = B[bi * SP_LD + lane];
+      B[k * SP_LD + lane] = d;
+      B[bi * SP_LD + lane] = c;
+    }
+    __syncthreads();
+    const double piv = A[k * SP_LD + k];
+    logdet += log(fabs(piv));
+    if (lane < n) {
+      cbuf[lane] = A[k * SP_LD + lane] / piv;
+      sbuf[lane] = B[k * SP_LD + lane] / piv;
+    }
+    __syncthreads();
+    if (lane < n) {
+      if (lane == k) {
+        for (int c = 0; c < n; ++c) {
+          A[k * SP_LD + c] = cbuf[c];
+          B[k * SP_LD + c] = sbuf[c];
+        }
+      } else {
+        const double f = A[lane * SP_LD + k];
+        for (int c = 0; c < n; ++c) {
+          A[lane * SP_LD + c] = fma(-f, cbuf[c], A[lane * SP_LD + c]);
+          B[lane * SP_LD + c] = fma(-f, sbuf[c], B[lane * SP_LD + c]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  int route = 1;
+  if (!singular) {
+    double ni = 0.0;  // 1-norm of column `lane` of the computed inverse
+    bool fin = true;
+    if (lane < n)
+      for (int r = 0; r < n; ++r) {
+        const double v = B[r * SP_LD + lane];
+        ni += fabs(v);
+        fin = fin && ((v - v) == 0.0);
+      }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) ni = fmax(ni, __shfl_xor(ni, s));
+    const bool allfin = __all(fin);
+    if (!allfin || !(1.0 / (n1 * ni) >= eps)) singular = true;
+  }
+  double* R = B;  // where the answer is
+  if (singular) {
+    // ---- 2. ginv(): Jacobi eigen-decomposition of K (A), eigenvectors in B
+    route = 2;
+    logdet = __longlong_as_double(0x7ff8000000000000LL);
+    __syncthreads();
+    (void)build();
+    if (lane < n)
+      for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
+    __syncthreads();
+    const int ne = n + (n & 1);  // even number of players; index n (if any) is a bye
+    const int half = ne / 2;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      double offd = 0.0, diag = 0.0;
+      if (lane < n)
+        for (int c = 0; c < n; ++c) {
+          const double v = A[lane * SP_LD + c];
+          if (c == lane) diag += v * v; else offd += v * v;
+        }
+      offd = wave_sum(offd);
+      diag = wave_sum(diag);
+      if (!(offd > 1e-30 * diag)) break;  // wave-uniform
+      for (int round = 0; round < ne - 1; ++round) {
+        // round-robin tournament: player ne-1 fixed, the others rotate
+        if (lane < half) {
+          int a = (lane == 0) ? ne - 1 : (round + lane) % (ne - 1);
+          int b = (round + ne - 1 - lane) % (ne - 1);
+          if (a > b) { const int x = a; a = b; b = x; }
+          double c = 1.0, sn = 0.0;
+          if (b < n) {
+            const double apq = A[a * SP_LD + b];
+            if (apq != 0.0) {
+              const double tau = (A[b * SP_LD + b] - A[a * SP_LD + a]) / (2.0 * apq);
+              const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              c = 1.0 / sqrt(1.0 + tt * tt);
+              sn = tt * c;
+            }
+          } else {
+            a = b = 0;  // bye: identity rotation on (0, 0), skipped below
+          }
+          pq[2 * lane] = a;
+          pq[2 * lane + 1] = b;
+          cbuf[lane] = c;
+          sbuf[lane] = sn;
+        }
+        __syncthreads();
+        if (lane < n) {  // columns: A <- A J, V <- V J (lane = row)
+          for (int k = 0; k < half; ++k) {
+            const int a = pq[2 * k], b = pq[2 * k + 1];
+            if (a == b) continue;
+            const double c = cbuf[k], sn = sbuf[k];
+            const double x = A[lane * SP_LD + a], z = A[lane * SP_LD + b];
+            A[lane * SP_LD + a] = c * x - sn * z;
+            A[lane * SP_LD + b] = sn * x + c * z;
+            const double u = B[lane * SP_LD + a], v = B[lane * SP_LD + b];
+            B[lane * SP_LD + a] = c * u - sn * v;
+            B[lane * SP_LD + b] = sn * u + c * v;
+          }
+        }
+        __syncthreads();
+        if (lane < n) {  // rows: A <- J' A (lane = column)
+          for (int k = 0; k < half; ++k) {
+            const int a = pq[2 * k], b = pq[2 * k + 1];
+            if (a == b) continue;
+            const double c = cbuf[k], sn = sbuf[k];
+            const double x = A[a * SP_LD + lane], z = A[b * SP_LD + lane];
+            A[a * SP_LD + lane] = c * x - sn * z;
+            A[b * SP_LD + lane] = sn * x + c * z;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    double lk = lane < n ? A[lane * SP_LD + lane] : 0.0;
+    double lmax = fabs(lk);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, s));
+    const double tol = 1.4901161193847656e-08 * lmax;  // sqrt(.Machine$double.eps) * d[1]
+    lam[lane] = (lane < n && fabs(lk) > tol) ? 1.0 / lk : 0.0;
+    __syncthreads();
+    if (lane < n)  // pseudo-inverse row `lane` into A (only its own row is overwritten)
+      for (int c = 0; c < n; ++c) {
+        double sacc = 0.0;
+        for (int k = 0; k < n; ++k) sacc = fma(B[lane * SP_LD + k] * lam[k], B[c * SP_LD + k], sacc);
+        A[lane * SP_LD + c] = sacc;
+      }
+    R = A;
+  }
+  __syncthreads();
+  SlowInv r;
+  r.R = R;
+  r.F = (R == A) ? B : A;
+  r.route = route;
+  r.logdet = logdet;
+  return r;
+}
+
+// log|det R| through an LU with partial pivoting (R's determinant(): dgetrf) of a copy of R in W.
+__device__ __forceinline__ double slow_logabsdet(int lane, int n, const double* R, double* W) {
+  if (lane < n)
+    for (int c = 0; c < n; ++c) W[lane * SP_LD + c] = R[lane * SP_LD + c];
+  __syncthreads();
+  double acc = 0.0;
+  for (int k = 0; k < n; ++k) {
+    double best = (lane >= k && lane < n) ? fabs(W[lane * SP_LD + k]) : -1.0;
+    int bi = lane;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const double ob = __shfl_xor(best, s);
+      const int oi = __shfl_xor(bi, s);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (!(best > 0.0)) return -__builtin_inf();                              // exactly singular
+    if (!(best < 1.7e308)) return __longlong_as_double(0x7ff8000000000000LL);  // not finite
+    if (lane < n && bi != k) {  // swap rows k and bi (lane = column)
+      const double a = W[k * SP_LD + lane], b = W[bi * SP_LD + lane];
+      W[k * SP_LD + lane] = b;
+      W[bi * SP_LD + lane] = a;
+    }
+    __syncthreads();
+    const double piv = W[k * SP_LD + k];
+    acc += log(fabs(piv));
+    if (lane > k && lane < n) {
+      const double f = W[lane * SP_LD + k] / piv;
+      for (int c = k + 1; c < n; ++c) W[lane * SP_LD + c] = fma(-f, W[k * SP_LD + c], W[lane * SP_LD + c]);
+    }
+    __syncthreads();
+  }
+  return acc;
+}
 
 __global__ __launch_bounds__(64) void small_slowpath_kernel(
     int M, const int64_t* __restrict__ off, const int64_t* __restrict__ off2,
@@ -127,7 +347,6 @@ __global__ __launch_bounds__(64) void small_slowpath_kernel(
   double* lam = sbuf + 64;         // eigenvalues
   int* pq = reinterpret_cast<int*>(lam + 64);  // [64]: pairs of the current round (p, q)
   const int lane = threadIdx.x;
-  const double eps = 2.220446049250313e-16;
   for (int i = blockIdx.x; i < M; i += gridDim.x) {
     if (info[i] == 0) continue;  // wave-uniform
     const int64_t o = off[i];
@@ -137,7 +356,7 @@ __global__ __launch_bounds__(64) void small_slowpath_kernel(
     __syncthreads();
     tbuf[lane] = lane < n ? t[o + lane] : 0.0;
     __syncthreads();
-    auto build = [&]() {  // lane r builds row r of K into A; returns its column... (symmetric)
+    const SlowInv sv = slow_solve_or_ginv(lane, n, A, B, cbuf, sbuf, lam, pq, [&]() {
       double colsum = 0.0;
       if (lane < n)
         for (int c = 0; c < n; ++c) {
@@ -147,168 +366,10 @@ __global__ __launch_bounds__(64) void small_slowpath_kernel(
           colsum += fabs(v);
         }
       return colsum;  // = 1-norm of column `lane` by symmetry
-    };
-    double n1 = build();
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) n1 = fmax(n1, __shfl_xor(n1, s));
-    if (lane < n)
-      for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
-    __syncthreads();
-    // ---- 1. solve(): Gauss-Jordan, partial pivoting
-    bool singular = false;
-    double logdet = 0.0;
-    for (int k = 0; k < n; ++k) {
-      double best = (lane >= k && lane < n) ? fabs(A[lane * SP_LD + k]) : -1.0;
-      int bi = lane;
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) {
-        const double ob = __shfl_xor(best, s);
-        const int oi = __shfl_xor(bi, s);
-        if (ob > best || (ob == best && oi < bi)) {
-          best = ob;
-          bi = oi;
-        }
-      }
-      if (!(best > 0.0) || !(best < 1.7e308)) {
-        singular = true;
-        break;
-      }
-      if (lane < n && bi != k) {  // swap rows k and bi (lane = column)
-        const double a = A[k * SP_LD + lane], b = A[bi * SP_LD + lane];
-        A[k * SP_LD + lane] = b;
-        A[bi * SP_LD + lane] = a;
-        const double c = B[k * SP_LD + lane], d = B[bi * SP_LD + lane];
-        B[k * SP_LD + lane] = d;
-        B[bi * SP_LD + lane] = c;
-      }
-      __syncthreads();
-      const double piv = A[k * SP_LD + k];
-      logdet += log(fabs(piv));
-      if (lane < n) {
-        cbuf[lane] = A[k * SP_LD + lane] / piv;
-        sbuf[lane] = B[k * SP_LD + lane] / piv;
-      }
-      __syncthreads();
-      if (lane < n) {
-        if (lane == k) {
-          for (int c = 0; c < n; ++c) {
-            A[k * SP_LD + c] = cbuf[c];
-            B[k * SP_LD + c] = sbuf[c];
-          }
-        } else {
-          const double f = A[lane * SP_LD + k];
-          for (int c = 0; c < n; ++c) {
-            A[lane * SP_LD + c] = fma(-f, cbuf[c], A[lane * SP_LD + c]);
-            B[lane * SP_LD + c] = fma(-f, sbuf[c], B[lane * SP_LD + c]);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    int route = 1;
-    if (!singular) {
-      double ni = 0.0;  // 1-norm of column `lane` of the computed inverse
-      bool fin = true;
-      if (lane < n)
-        for (int r = 0; r < n; ++r) {
-          const double v = B[r * SP_LD + lane];
-          ni += fabs(v);
-          fin = fin && ((v - v) == 0.0);
-        }
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) ni = fmax(ni, __shfl_xor(ni, s));
-      const bool allfin = __all(fin);
-      if (!allfin || !(1.0 / (n1 * ni) >= eps)) singular = true;
-    }
-    double* R = B;  // where the answer is
-    if (singular) {
-      // ---- 2. ginv(): Jacobi eigen-decomposition of K (A), eigenvectors in B
-      route = 2;
-      logdet = __longlong_as_double(0x7ff8000000000000LL);
-      __syncthreads();
-      (void)build();
-      if (lane < n)
-        for (int c = 0; c < n; ++c) B[lane * SP_LD + c] = (c == lane) ? 1.0 : 0.0;
-      __syncthreads();
-      const int ne = n + (n & 1);  // even number of players; index n (if any) is a bye
-      const int half = ne / 2;
-      for (int sweep = 0; sweep < 40; ++sweep) {
-        double offd = 0.0, diag = 0.0;
-        if (lane < n)
-          for (int c = 0; c < n; ++c) {
-            const double v = A[lane * SP_LD + c];
-            if (c == lane) diag += v * v; else offd += v * v;
-          }
-        offd = wave_sum(offd);
-        diag = wave_sum(diag);
-        if (!(offd > 1e-30 * diag)) break;  // wave-uniform
-        for (int round = 0; round < ne - 1; ++round) {
-          // round-robin tournament: player ne-1 fixed, the others rotate
-          if (lane < half) {
-            int a = (lane == 0) ? ne - 1 : (round + lane) % (ne - 1);
-            int b = (round + ne - 1 - lane) % (ne - 1);
-            if (a > b) { const int x = a; a = b; b = x; }
-            double c = 1.0, sn = 0.0;
-            if (b < n) {
-              const double apq = A[a * SP_LD + b];
-              if (apq != 0.0) {
-                const double tau = (A[b * SP_LD + b] - A[a * SP_LD + a]) / (2.0 * apq);
-                const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                c = 1.0 / sqrt(1.0 + tt * tt);
-                sn = tt * c;
-              }
-            } else {
-              a = b = 0;  // bye: identity rotation on (0, 0), skipped below
-            }
-            pq[2 * lane] = a;
-            pq[2 * lane + 1] = b;
-            cbuf[lane] = c;
-            sbuf[lane] = sn;
-          }
-          __syncthreads();
-          if (lane < n) {  // columns: A <- A J, V <- V J (lane = row)
-            for (int k = 0; k < half; ++k) {
-              const int a = pq[2 * k], b = pq[2 * k + 1];
-              if (a == b) continue;
-              const double c = cbuf[k], sn = sbuf[k];
-              const double x = A[lane * SP_LD + a], z = A[lane * SP_LD + b];
-              A[lane * SP_LD + a] = c * x - sn * z;
-              A[lane * SP_LD + b] = sn * x + c * z;
-              const double u = B[lane * SP_LD + a], v = B[lane * SP_LD + b];
-              B[lane * SP_LD + a] = c * u - sn * v;
-              B[lane * SP_LD + b] = sn * u + c * v;
-            }
-          }
-          __syncthreads();
-          if (lane < n) {  // rows: A <- J' A (lane = column)
-            for (int k = 0; k < half; ++k) {
-              const int a = pq[2 * k], b = pq[2 * k + 1];
-              if (a == b) continue;
-              const double c = cbuf[k], sn = sbuf[k];
-              const double x = A[a * SP_LD + lane], z = A[b * SP_LD + lane];
-              A[a * SP_LD + lane] = c * x - sn * z;
-              A[b * SP_LD + lane] = sn * x + c * z;
-            }
-          }
-          __syncthreads();
-        }
-      }
-      double lk = lane < n ? A[lane * SP_LD + lane] : 0.0;
-      double lmax = fabs(lk);
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, s));
-      const double tol = 1.4901161193847656e-08 * lmax;  // sqrt(.Machine$double.eps) * d[1]
-      lam[lane] = (lane < n && fabs(lk) > tol) ? 1.0 / lk : 0.0;
-      __syncthreads();
-      if (lane < n)  // pseudo-inverse row `lane` into A (only its own row is overwritten)
-        for (int c = 0; c < n; ++c) {
-          double sacc = 0.0;
-          for (int k = 0; k < n; ++k) sacc = fma(B[lane * SP_LD + k] * lam[k], B[c * SP_LD + k], sacc);
-          A[lane * SP_LD + c] = sacc;
-        }
-      R = A;
-    }
-    __syncthreads();
+    });
+    const double* R = sv.R;
+    const int route = sv.route;
+    const double logdet = sv.logdet;
     // ---- output (R symmetric up to rounding: row `lane` read as column `lane`)
     if (lane < n) {
       double vi = 0.0;
@@ -334,6 +395,227 @@ __global__ __launch_bounds__(64) void small_slowpath_kernel(
       if (logdet_out != nullptr) logdet_out[i] = logdet;
       if (route_out != nullptr) route_out[i] = route;
     }
+  }
+}
+
+// ------------------------------------------------------------------ slow path of the evaluations
+// logL_GP_mod / gr_GP_mod (CF:181-201, 304-332) and logL_GP / gr_GP (CF:174-179, 279-302) for the
+// slots whose matrix the sweep of indiv_eval_kernel flagged: the reference does not stop there, it
+// evaluates with `tryCatch(solve(.), error = ginv(.))` (CF:133, 177, 285) and takes the
+// log-determinant from the LU of that inverse (dmvnorm, CF:27: `- determinant(inv)$modulus`).
+// Same formulas, term by term, from R = solve() / ginv() of K (mode 0) or K + C (mode 1):
+//   f  = (n log 2pi - log|det R| + z' R z) / 2 + [mode 0] sum(R o C) / 2
+//   W  = (R z)(R z)' - R + [mode 0] R C R;  g = -(tr(W K_1) / 2, tr(W K_2) / 2, sigma tr W)
+// One wavefront per flagged slot; workgroup b looks at slots 64 b .. 64 b + 63 (one load) and
+// leaves at once when none is flagged. info stays as the sweep set it (nonzero = answered here).
+// Parity with R is UNPINNED for this path (no reference fixture reaches it); checked against the
+// oracle's restatement of the same formulas.
+// C[r][c] in the packed layout of indiv_gather_cov_kernel
+__device__ __forceinline__ double cpack_el(const double* __restrict__ Cq, int nt, int r, int c) {
+  return Cq[(int64_t)(((c >> 2) * 64 + ((c & 3) << 4) + (r & 15)) * nt + (r >> 4))];
+}
+
+__global__ __launch_bounds__(64) void indiv_eval_slowpath_kernel(
+    int nsel, const int* __restrict__ sel, const int64_t* __restrict__ off,
+    const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
+    const double* __restrict__ theta, int tstride, const double* __restrict__ mean,
+    const double* __restrict__ cpack, int nt, int nc, int mode, int want_grad,
+    double* __restrict__ f_out, double* __restrict__ g_out, const int* __restrict__ info) {
+  const int lane = threadIdx.x;
+  const int base = (int)blockIdx.x * 64;
+  const int mine = (base + lane < nsel) ? info[base + lane] : 0;
+  unsigned long long mask = __ballot(mine != 0);
+  if (mask == 0ull) return;
+  extern __shared__ __attribute__((aligned(16))) double sp[];
+  double* A = sp;
+  double* B = sp + 64 * SP_LD;
+  double* tbuf = B + 64 * SP_LD;
+  double* cbuf = tbuf + 64;
+  double* sbuf = cbuf + 64;
+  double* lam = sbuf + 64;
+  int* pq = reinterpret_cast<int*>(lam + 64);
+  double* zbuf = lam + 128;
+  double* abuf = zbuf + 64;
+  while (mask != 0ull) {
+    const int io = base + (__ffsll((long long)mask) - 1);
+    mask &= mask - 1ull;
+    const int i = sel ? sel[io] : io;
+    const int64_t o = off[i];
+    const int n = (int)(off[i + 1] - o);
+    const double* th = theta + (int64_t)io * tstride;
+    const double sigma = th[2];
+    const SEParams p = se_params(th[0], th[1], sigma);
+    const double* Cq = cpack ? cpack + (int64_t)i * (16 * nt * nc) : nullptr;
+    const bool with_c = (mode == 0 && Cq != nullptr);
+    const bool add_c = (mode == 1 && Cq != nullptr);
+    __syncthreads();
+    tbuf[lane] = lane < n ? t[o + lane] : 0.0;
+    zbuf[lane] = lane < n ? (y[o + lane] - mean[idx[o + lane]]) : 0.0;
+    __syncthreads();
+    const SlowInv sv = slow_solve_or_ginv(lane, n, A, B, cbuf, sbuf, lam, pq, [&]() {
+      double colsum = 0.0;
+      if (lane < n)
+        for (int c = 0; c < n; ++c) {
+          const double d = tbuf[lane] - tbuf[c];
+          double v = (c == lane) ? (p.eth1 + p.sig2) : exp(p.th1 - p.h * d * d);
+          if (add_c) v += cpack_el(Cq, nt, lane, c);
+          A[lane * SP_LD + c] = v;
+          colsum += fabs(v);
+        }
+      return colsum;
+    });
+    const double* R = sv.R;
+    double* F = sv.F;
+    const double ldr = slow_logabsdet(lane, n, R, F);
+    double alpha = 0.0, rc = 0.0;
+    if (lane < n)
+      for (int c = 0; c < n; ++c) {
+        alpha = fma(R[lane * SP_LD + c], zbuf[c], alpha);
+        if (with_c) rc = fma(R[lane * SP_LD + c], cpack_el(Cq, nt, lane, c), rc);
+      }
+    abuf[lane] = alpha;
+    const double ssq = wave_sum(zbuf[lane] * alpha);
+    const double cor = wave_sum(rc);
+    const double f = 0.5 * ((double)n * LOG_2PI - ldr + ssq) + 0.5 * cor;
+    __syncthreads();  // abuf visible, the LU's copy in F no longer needed
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (want_grad) {
+      if (with_c) {
+        if (lane < n)
+          for (int c = 0; c < n; ++c) {  // F = R C
+            double a = 0.0;
+            for (int k = 0; k < n; ++k) a = fma(R[lane * SP_LD + k], cpack_el(Cq, nt, k, c), a);
+            F[lane * SP_LD + c] = a;
+          }
+        __syncthreads();
+      }
+      if (lane < n)
+        for (int c = 0; c < n; ++c) {
+          double wv = alpha * abuf[c] - R[lane * SP_LD + c];
+          if (with_c) {
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a = fma(F[lane * SP_LD + j], R[j * SP_LD + c], a);
+            wv += a;
+          }
+          const double d = tbuf[lane] - tbuf[c];
+          const double gr = p.h * d * d;
+          const double k1 = (c == lane) ? p.eth1 : exp(p.th1 - gr);       // CF:289: sigma = 0
+          const double k2 = (c == lane) ? 0.0 : gr * exp(p.th1 - gr);     // CF:272-277, zero diagonal
+          s1 = fma(wv, k1, s1);
+          s2 = fma(wv, k2, s2);
+          s3 += (c == lane) ? wv : 0.0;
+        }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      s3 = wave_sum(s3);
+    }
+    if (lane == 0) {
+      f_out[io] = f;
+      if (want_grad) {
+        g_out[3 * (int64_t)io + 0] = -0.5 * s1;
+        g_out[3 * (int64_t)io + 1] = -0.5 * s2;
+        g_out[3 * (int64_t)io + 2] = -sigma * s3;
+      }
+    }
+  }
+}
+
+// pred_gp (MG:172-180) for the individuals whose cov_tn_tn the sweep flagged: inv_mat from
+// solve() / ginv() (MG:173), then every target of that individual by this one wavefront.
+// mean_grid != nullptr: the batched entry point's device-resident mean (gathered through idx).
+__device__ __attribute__((noinline)) void pred_gp_slow_body(
+    int n, const double* __restrict__ tn, const double* __restrict__ yn,
+    const double* __restrict__ mean_obs, const int* __restrict__ idx_n, int T,
+    const double* __restrict__ ts, const double* __restrict__ mean_pred,
+    const int* __restrict__ idx_t, const double* __restrict__ mean_grid,
+    const double* __restrict__ cov, int64_t ldc, const double* __restrict__ theta,
+    double* __restrict__ out_mean, double* __restrict__ out_var, double* sp) {
+  const int lane = threadIdx.x;
+  double* A = sp;
+  double* B = sp + 64 * SP_LD;
+  double* tbuf = B + 64 * SP_LD;
+  double* cbuf = tbuf + 64;
+  double* sbuf = cbuf + 64;
+  double* lam = sbuf + 64;
+  int* pq = reinterpret_cast<int*>(lam + 64);
+  double* zbuf = lam + 128;
+  int* ibuf = reinterpret_cast<int*>(zbuf + 128);
+  const SEParams p = se_params(theta[0], theta[1], theta[2]);
+  const bool rv = lane < n;
+  const double tr = rv ? tn[lane] : 0.0;
+  const int ir = (rv && idx_n) ? idx_n[lane] : 0;
+  const double mo = !rv ? 0.0 : (mean_grid ? mean_grid[ir] : mean_obs[lane]);
+  __syncthreads();
+  tbuf[lane] = tr;
+  zbuf[lane] = rv ? (yn[lane] - mo) : 0.0;
+  ibuf[lane] = ir;
+  __syncthreads();
+  const SlowInv sv = slow_solve_or_ginv(lane, n, A, B, cbuf, sbuf, lam, pq, [&]() {
+    double colsum = 0.0;
+    if (rv)
+      for (int c = 0; c < n; ++c) {
+        const double d = tr - tbuf[c];
+        double v = (c == lane) ? (p.eth1 + p.sig2) : exp(p.th1 - p.h * d * d);
+        if (cov != nullptr) v += cov[(int64_t)ibuf[c] * ldc + ir];
+        A[lane * SP_LD + c] = v;
+        colsum += fabs(v);
+      }
+    return colsum;
+  });
+  const double* R = sv.R;
+  double alpha = 0.0;
+  if (rv)
+    for (int c = 0; c < n; ++c) alpha = fma(R[lane * SP_LD + c], zbuf[c], alpha);
+  for (int j = 0; j < T; ++j) {
+    const double tt = ts[j];
+    const int it = idx_t ? idx_t[j] : 0;
+    const double d = tr - tt;
+    double kv = rv ? exp(p.th1 - p.h * d * d) : 0.0;
+    if (rv && cov != nullptr) kv += cov[(int64_t)it * ldc + ir];
+    __syncthreads();
+    cbuf[lane] = kv;
+    __syncthreads();
+    double u = 0.0;
+    if (rv)
+      for (int c = 0; c < n; ++c) u = fma(R[lane * SP_LD + c], cbuf[c], u);
+    const double q = wave_sum(kv * u);
+    const double m = wave_sum(kv * alpha);
+    if (lane == 0) {
+      const double ctt = (cov != nullptr) ? cov[(int64_t)it * ldc + it] : 0.0;
+      const double mp = mean_grid ? mean_grid[it] : mean_pred[j];
+      out_mean[j] = mp + m;
+      out_var[j] = (p.eth1 + p.sig2 + ctt) - q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void pred_gp_slowpath_kernel(
+    int n, const double* __restrict__ tn, const double* __restrict__ yn,
+    const double* __restrict__ mean_obs, const int* __restrict__ idx_n, int T,
+    const double* __restrict__ ts, const double* __restrict__ mean_pred,
+    const int* __restrict__ idx_t, const double* __restrict__ cov, int64_t ldc,
+    const double* __restrict__ theta, double* __restrict__ out_mean,
+    double* __restrict__ out_var, const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];
+  if (info[0] == 0) return;
+  pred_gp_slow_body(n, tn, yn, mean_obs, idx_n, T, ts, mean_pred, idx_t, nullptr, cov, ldc, theta,
+                    out_mean, out_var, sp);
+}
+
+__global__ __launch_bounds__(64) void pred_gp_batched_slowpath_kernel(
+    int B, const int64_t* __restrict__ off_n, const double* __restrict__ tn,
+    const double* __restrict__ yn, const int* __restrict__ idx_n,
+    const int64_t* __restrict__ off_t, const double* __restrict__ ts,
+    const int* __restrict__ idx_t, const double* __restrict__ mean_grid,
+    const double* __restrict__ cov, int64_t ldc, const double* __restrict__ theta, int tstride,
+    double* __restrict__ out_mean, double* __restrict__ out_var, const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    if (info[b] == 0) continue;  // wave-uniform
+    const int64_t on = off_n[b], ot = off_t[b];
+    pred_gp_slow_body((int)(off_n[b + 1] - on), tn + on, yn + on, nullptr, idx_n + on,
+                      (int)(off_t[b + 1] - ot), ts + ot, nullptr, idx_t + ot, mean_grid, cov, ldc,
+                      theta + (int64_t)b * tstride, out_mean + ot, out_var + ot, sp);
   }
 }
 
@@ -1498,6 +1780,10 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
     const unsigned long long rs_t0 = __builtin_readcyclecounter();
 #endif
     lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
+    // a covariance the sweep flagged: the reference evaluates it through solve() / ginv()
+    // (CF:133); that evaluation lives in indiv_eval_slowpath_kernel, so this problem stops here
+    // with status 6 and the host solves it again through the lock-step route
+    if (info != 0 && info != -999) st->status = 6;
 #ifdef MAGMA_RES_STAMPS
     if (helped && lane == 0) atomicAdd(&g_res_stamps[12], __builtin_readcyclecounter() - rs_t0);  // tell
     if (helped && lane == 0) atomicAdd(&g_res_stamps[13], rs_t0 - rs_e0);  // start -> tell
@@ -1868,19 +2154,22 @@ int launch_estep_scatter(int M, int nmax, const int64_t* off, const double* t, c
   return check_hip(hipGetLastError(), "estep_scatter");
 }
 
+// Dynamic LDS above 64 KB needs the attribute once per device and kernel (which: 0..3).
+static int slowpath_lds_attr(const void* fn, size_t dyn, int which) {
+  static AttrOnce once[4];
+  return once[which].ensure([&] {
+    return check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
+                     "slow path LDS size");
+  });
+}
+
 int launch_small_slowpath(int M, const int64_t* off, const int64_t* off2, const double* t,
                           const double* y, const int* idx, const double* theta, int tstride,
                           const int* info, double* Kinv, double* v, double* logdet, double* P,
                           int64_t ldp, double* w, int* route, hipStream_t st) {
   if (M <= 0) return 0;
   const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
-  static AttrOnce once;
-  if (int rc = once.ensure([&] {
-        return check_hip(hipFuncSetAttribute((const void*)small_slowpath_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn),
-                         "slow path LDS size");
-      }))
-    return rc;
+  if (int rc = slowpath_lds_attr((const void*)small_slowpath_kernel, dyn, 0)) return rc;
   const int grid = M < 512 ? M : 512;  // unflagged individuals cost one load each
   hipLaunchKernelGGL(small_slowpath_kernel, dim3(grid), dim3(64), dyn, st, M, off, off2, t, y, idx,
                      theta, tstride, info, Kinv, v, logdet, P, ldp, w, route);
@@ -1942,7 +2231,14 @@ int launch_indiv_eval(int nsel, const int* sel, int nmax, const int64_t* off, co
                                mode, want_grad, f, g, info, st)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
-  return rc;
+  if (rc) return rc;
+  // the slots the sweep flagged: solve() / ginv(), as the reference's tryCatch does
+  const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
+  if (int r2 = slowpath_lds_attr((const void*)indiv_eval_slowpath_kernel, dyn, 1)) return r2;
+  hipLaunchKernelGGL(indiv_eval_slowpath_kernel, dim3((nsel + 63) / 64), dim3(64), dyn, st, nsel, sel,
+                     off, t, y, idx, theta, tstride, mean, cpack, cpack_ldp(nmax) / 16,
+                     small_template_nmax(nmax), mode, want_grad, f, g, info);
+  return check_hip(hipGetLastError(), "indiv_eval slow path");
 }
 
 // Cap on the workgroups (= compute units) of the device-resident M-step; 0 = every compute unit.
@@ -2100,7 +2396,12 @@ int launch_pred_gp(int n, const double* tn, const double* yn, const double* mean
                      info, chunk)
   MAGMA_DISPATCH_NMAX(n, CALL);
 #undef CALL
-  return check_hip(hipGetLastError(), "pred_gp");
+  if (int rc = check_hip(hipGetLastError(), "pred_gp")) return rc;
+  const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
+  if (int rc = slowpath_lds_attr((const void*)pred_gp_slowpath_kernel, dyn, 2)) return rc;
+  hipLaunchKernelGGL(pred_gp_slowpath_kernel, dim3(1), dim3(64), dyn, st, n, tn, yn, mean_obs, idx_n, T,
+                     ts, mean_pred, idx_t, cov, ldc, theta, out_mean, out_var, info);
+  return check_hip(hipGetLastError(), "pred_gp slow path");
 }
 
 int launch_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, const double* tn,
@@ -2118,7 +2419,13 @@ int launch_pred_gp_batched(int B, int nmax, int tmax, const int64_t* off_n, cons
                      out_var, info, chunk)
   MAGMA_DISPATCH_NMAX(nmax, CALL);
 #undef CALL
-  return check_hip(hipGetLastError(), "pred_gp_batched");
+  if (int rc = check_hip(hipGetLastError(), "pred_gp_batched")) return rc;
+  const size_t dyn = (size_t)SP_LDS_DOUBLES * sizeof(double);
+  if (int rc = slowpath_lds_attr((const void*)pred_gp_batched_slowpath_kernel, dyn, 3)) return rc;
+  hipLaunchKernelGGL(pred_gp_batched_slowpath_kernel, dim3(B < 512 ? B : 512), dim3(64), dyn, st, B,
+                     off_n, tn, yn, idx_n, off_t, ts, idx_t, mean_grid, cov, ldc, theta, tstride,
+                     out_mean, out_var, info);
+  return check_hip(hipGetLastError(), "pred_gp_batched slow path");
 }
 
 }  // namespace magma

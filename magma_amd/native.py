@@ -15,7 +15,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_
 
 class EmStats(C.Structure):
     _fields_ = [("theta0_evals", C.c_int64), ("indiv_rounds", C.c_int64), ("indiv_evals", C.c_int64),
-                ("common_evals", C.c_int64), ("flagged", C.c_int64)]
+                ("common_evals", C.c_int64), ("flagged", C.c_int64),
+                ("slow_resolved", C.c_int64)]
 
 
 def _hp(a):
