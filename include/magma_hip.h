@@ -12,14 +12,23 @@
  *    after magma_stream_sync(stream) (or any later work on the same stream).
  *  - Return value: 0 = ok, >0 = error; magma_last_error() gives the message (thread-local).
  *    A covariance that is not numerically positive definite is NOT an error: the per-matrix
- *    `info` output is non-zero (index of the first bad pivot, LAPACK dpotrf style). For the small
- *    per-individual matrices of the E-step and of magma_kern_to_inv_batched such a matrix then
- *    goes through the reference's `tryCatch(solve(.), error -> MASS::ginv(.))` (CF:133,161) on the
- *    device: LU with partial pivoting, and the pseudo-inverse (symmetric Jacobi, MASS::ginv's
- *    tolerance) when that is singular to machine precision -- parity with R unpinned, no
- *    reference fixture reaches it. The M-step objective of such a matrix evaluates to NaN (a
- *    failed trial point for the optimiser); the dense N x N objects report info and the host
- *    decides.
+ *    `info` output is non-zero (index of the first bad pivot, LAPACK dpotrf style). Every SMALL
+ *    (per-individual, n <= 64) matrix -- the E-step's K_i, magma_kern_to_inv_batched, the M-step
+ *    objectives (magma_indiv_eval, magma_indiv_mstep, magma_train_new_gp) and cov_tn_tn of the
+ *    predictions -- then goes through the reference's `tryCatch(solve(.), error -> MASS::ginv(.))`
+ *    (CF:133,161,177,285; MG:173) on the device: LU with partial pivoting, and the pseudo-inverse
+ *    (symmetric Jacobi, MASS::ginv's tolerance) when that is singular to machine precision --
+ *    parity with R unpinned, no reference fixture reaches it. (The device-resident M-step reports
+ *    status 6 for a problem whose start is flagged; see magma_indiv_mstep_resident.)
+ *    DELIBERATE DEVIATION for the dense N x N objects (K_0, the hyper-posterior precision of
+ *    CF:387 / MG:123, an individual with n > 64): no pseudo-inverse is computed. `info` reports
+ *    the flag and the driver calls (magma_e_step, magma_em_iteration, magma_training, ...) return
+ *    status 5 with a message naming the matrix. Reason: the precision K_0^-1 + sum_i K_i^-1 is a
+ *    sum of positive definite matrices; it fails the sweep only when K_0 itself is singular to
+ *    rounding (theta_0 at an extreme the optimiser should not be left at), where ginv() of an
+ *    N = 2,000 .. 8,000 matrix would hand the M-step a rank-deficient cov that R itself then
+ *    inverts again through the same tryCatch -- a result dominated by the 1.5e-8 cut-off, not by
+ *    the data. The caller is told instead of being given that.
  *  - Ragged dataset: individual i owns rows off[i]..off[i+1]-1 of t / y / idx (timestamps
  *    ascending within an individual, as the reference assumes: CF:74,95). idx[] is the int32
  *    position of each timestamp in the sorted union grid (replaces the `paste0('X', t)` names of
@@ -70,7 +79,8 @@ int magma_prof_reset(void);
  * "resident_help" (default 1): in the device-resident M-step, wavefronts that find no individual
  * left take tile rows of K and column blocks of the product stages of the evaluations still
  * running in their workgroup (identical results; 0 = off; bit 1 = launch every compute unit even
- * for a handful of individuals, for tests).
+ * for a handful of individuals, for tests). "resident_slow_path" (default 0): see
+ * magma_indiv_mstep_resident, status 6.
  * "dag_walker" (default 2): who walks the chain of diagonal tiles of the one-launch inverse -- 2: one
  * workgroup whose wavefronts work a block step ahead of the 64 x 64 factor, 1: one workgroup in
  * lock step, 0: a task per block step. "dag_max_block_rows" (default 64): the one-launch inverse
@@ -175,7 +185,12 @@ int magma_spd_inverse_static(int N, double* A, double* d_logdet, int* d_info, vo
  * (the hyper-posterior is fixed during an M-step, so the gather is done once and every
  * evaluation streams contiguous data); NULL = C is zero.
  * The common-HP objective (CF:203-234, 334-368) is the sum of these over individuals with
- * theta_stride = 0. */
+ * theta_stride = 0.
+ * info_out[b] != 0: the Cholesky-type sweep found that slot's covariance not positive definite to
+ * rounding. Like the reference (`tryCatch(solve(.), error = ginv(.))`, CF:133, 177, 285) the call
+ * does not stop there: f_out / g_out of that slot come from LU with partial pivoting or, when that
+ * is singular to machine precision, the pseudo-inverse (MASS::ginv's tolerance), with the
+ * log-determinant from the LU of that inverse as in dmvnorm (CF:27). info_out keeps the flag. */
 int magma_indiv_eval(int mode, int M, int nmax, const int64_t* off, const double* t,
                      const double* y, const int* idx, const double* theta, int theta_stride,
                      const double* mean, const double* cpack, int want_grad, const int* sel,
@@ -209,7 +224,14 @@ int magma_indiv_mstep(int mode, int M, int nmax, const int64_t* off, const doubl
  * iters[M], nfev[M], status[M] out (same meaning as above). order (optional): a permutation of
  * 0..M-1, the order in which individuals are started -- the launch lasts as long as its longest
  * chain of evaluations, so start the expected longest first (e.g. by the previous EM
- * iteration's nfev); results do not depend on it. m <= 5. Asynchronous on stream. */
+ * iteration's nfev); results do not depend on it. m <= 5. Asynchronous on stream.
+ * status 6 (this entry point only): the covariance at the problem's START point is not positive
+ * definite to rounding. The solve() / ginv() evaluation the reference makes there (CF:133) is not
+ * inside this kernel: solve such problems with magma_indiv_mstep (magma_m_step does that by
+ * itself). A flagged TRIAL point inside a line search gives a non-finite value and the search
+ * bisects towards its best point -- a deliberate deviation: the reference's value there is
+ * +37 per null direction plus rounding noise of the pseudo-inverse's determinant and only serves
+ * to reject the step; option "resident_slow_path" = 1 turns those into status 6 as well. */
 int magma_indiv_mstep_resident(int mode, int M, int nmax, const int64_t* off, const double* t,
                                const double* y, const int* idx, const double* mean,
                                const double* cpack, const double* theta0, const int* order,
@@ -331,6 +353,13 @@ int magma_m_step(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0, cons
 /* logL_monitoring (CF:236-264) at the given hyper-parameters against the resident hyper-posterior */
 int magma_logl_monitoring(magma_ctx* ctx, magma_dataset* ds, const double* h_theta0,
                           const double* h_theta_i, int theta_stride, double* h_out);
+/* Sum over ALL individuals (every rank's shard, all-reduced) of logL_GP_mod and, with want_grad, of
+ * gr_GP_mod against the resident hyper-posterior: logL_GP_mod_common_hp / gr_GP_mod_common_hp
+ * (CF:203-234, 334-368) with theta_stride 0 (one triple; identical timestamps then invert once,
+ * CF:221-224), the individual part of logL_monitoring (CF:254-261) with theta_stride 3.
+ * h_out4 = (sum f, sum g1, sum g2, sum g3). */
+int magma_sum_fi(magma_ctx* ctx, magma_dataset* ds, const double* h_theta_i, int theta_stride,
+                 int want_grad, double* h_out4);
 /* Body of training's loop (MG:32-75): e_step, m_step, logL_monitoring(hp), logL_monitoring(new hp)
  * -> h_logl2 (NaN, NaN when the M-step produced a NaN hyper-parameter, MG:46-51). A failed
  * factorisation in the E-step is an error (status 5). */

@@ -7,7 +7,8 @@ from .api import (kernel, kernel_mu, mat_dist, deriv_hp1, deriv_hp2, dmvnorm, up
                   logL_GP_mod, gr_GP_mod, logL_GP_mod_common_hp, gr_GP_mod_common_hp,
                   logL_monitoring, e_step, m_step, training, train_new_gp, posterior_mu, pred_gp,
                   full_algo, posterior_mu_resident, pred_gp_batched)
-from .engine import Dataset, Engine, HipBackend, Comm
+from .engine import Dataset, HipBackend
+from .native import NativeEngine
 from .lbfgsb import minimize_batch
 from .io import read_csv2, split_by
 
@@ -15,5 +16,5 @@ __all__ = ["kernel", "kernel_mu", "mat_dist", "deriv_hp1", "deriv_hp2", "dmvnorm
            "update_mean", "kern_to_cov", "kern_to_inv", "logL_GP", "gr_GP",
            "logL_GP_mod", "gr_GP_mod", "logL_GP_mod_common_hp", "gr_GP_mod_common_hp",
            "logL_monitoring", "e_step", "m_step", "training", "train_new_gp", "posterior_mu",
-           "pred_gp", "full_algo", "posterior_mu_resident", "pred_gp_batched", "Dataset", "Engine", "HipBackend", "Comm", "minimize_batch",
+           "pred_gp", "full_algo", "posterior_mu_resident", "pred_gp_batched", "Dataset", "HipBackend", "NativeEngine", "minimize_batch",
            "read_csv2", "split_by"]

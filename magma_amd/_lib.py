@@ -94,6 +94,7 @@ SIGNATURES = {
     "magma_e_step": (_i, [_p, _p, _p, _p, _i, _d, _p, _i, C.POINTER(_i), C.POINTER(_d)]),
     "magma_m_step": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
     "magma_logl_monitoring": (_i, [_p, _p, _p, _p, _i, C.POINTER(_d)]),
+    "magma_sum_fi": (_i, [_p, _p, _p, _i, _i, _p]),
     "magma_em_iteration": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "magma_training": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, C.POINTER(_i),
                             C.POINTER(_i), _p]),

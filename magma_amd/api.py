@@ -13,8 +13,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .engine import Dataset, Engine, HipBackend, Comm, unique_in_order, _ptr
-from .lbfgsb import minimize_batch
+from .engine import Dataset, HipBackend, unique_in_order, _ptr
+from .native import NativeEngine, engine_for_job
 
 
 # ------------------------------------------------------------------ kernels (host, CF:36-57)
@@ -62,16 +62,6 @@ def _hp_dict(theta0, theta_i, ids):
 
 def _as_db(x):
     return {k: np.asarray(v) for k, v in x.items()}
-
-
-def _dist_comm():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return Comm(dist)
-    except Exception:  # pragma: no cover
-        pass
-    return Comm(None)
 
 
 # ------------------------------------------------------------------ covariance builders
@@ -349,9 +339,9 @@ def _engine_with_posterior(db, mean, new_cov):
     ds = Dataset(_as_db(db), extra_timestamps=labels)
     if ds.N != labels.size:
         raise KeyError("db has timestamps missing from the covariance's dimnames")
-    eng = Engine(ds, comm=_dist_comm())
+    eng = engine_for_job(ds)
     mvec = np.asarray(mean["Output"], float)[np.argsort(mean["Timestamp"], kind="stable")]
-    eng.be.set_mean_cov(mvec, cov)
+    eng.set_mean_cov(mvec, cov)
     return eng
 
 
@@ -393,7 +383,7 @@ def _param_from_engine(eng):
 def e_step(db, m_0, kern_0, kern_i, hp):
     """CF:371-395."""
     _check_kern(kern_0, kern_i)
-    eng = Engine(Dataset(_as_db(db)), comm=_dist_comm())
+    eng = engine_for_job(Dataset(_as_db(db)))
     th0, thi = _hp_arrays(hp, eng.ds.ids)
     info = eng.e_step(th0, thi, float(np.mean(thi[:, 2])), m_0)
     if info != 0:
@@ -417,13 +407,10 @@ def training(db, prior_mean, ini_hp, kern_0, kern_i, common_hp=True, trace=None,
     import time
     t1 = time.time()
     if engine is None:
-        comm = _dist_comm()
-        if comm.world == 1:
-            # the whole loop inside the library: ONE call (magma_training) per fit
-            from .native import NativeEngine
-            engine = NativeEngine(Dataset(_as_db(db)))
-        else:  # ranks of a torch.distributed job: the Python-driven engine over that group
-            engine = Engine(Dataset(_as_db(db)), comm=comm)
+        # the whole loop inside the library: ONE call (magma_training) per fit; in a
+        # torch.distributed job every rank calls this with the same db and the library's callback
+        # communicator sums over that group
+        engine = engine_for_job(Dataset(_as_db(db)))
     eng = engine
     th0, thi, cv = eng.training(prior_mean, ini_hp["theta_0"], ini_hp["theta_i"], common_hp,
                                 trace=trace)
@@ -458,14 +445,13 @@ def train_new_gp(db, mean_mu, cov_mu, ini_hp_i, kern_i):
         new_cov = cm[np.ix_(pos, pos)]
     else:
         new_cov = 0.0
-    be = _indiv_problem(db, mean, new_cov)
-
-    def ev(x, act):
-        return be.indiv_eval(x, want_grad=True, mode=1)
-    r = minimize_batch(np.asarray(ini_hp_i, dtype=np.float64)[None, :], ev)
-    new_hp = r["x"][0]
-    if np.any(np.isnan(new_hp)):
-        new_hp = np.asarray(ini_hp_i, dtype=np.float64)
+    from .native import train_new_gp as native_train_new_gp
+    order = np.argsort(t, kind="stable")
+    y = np.asarray(db["Output"], dtype=np.float64)[order]
+    mean = np.full(t.size, mean[0]) if mean.size == 1 else mean[order]
+    cov = None if np.ndim(new_cov) == 0 else np.ascontiguousarray(np.asarray(new_cov, float)[np.ix_(order, order)])
+    # one native call: the optimiser and MG:97-101's NaN rule run inside the library
+    new_hp, _ = native_train_new_gp(t[order], y, mean, cov, np.asarray(ini_hp_i, dtype=np.float64))
     return {"theta": new_hp[:2], "sigma": new_hp[2]}
 
 
@@ -475,7 +461,7 @@ def posterior_mu(db, new_db, timestamps, m_0, kern_0, kern_i, hp, pen_diag=0.1):
     _check_kern(kern_0, kern_i)
     extra = np.concatenate([np.asarray(timestamps, float).ravel(),
                             np.asarray(new_db["Timestamp"], float).ravel()])
-    eng = Engine(Dataset(_as_db(db), extra_timestamps=extra), comm=_dist_comm())
+    eng = engine_for_job(Dataset(_as_db(db), extra_timestamps=extra))
     th0, thi = _hp_arrays(hp, eng.ds.ids)
     if isinstance(pen_diag, str):
         pen_diag = float(np.mean(thi[:, 2]))
@@ -540,14 +526,14 @@ def pred_gp(db, timestamps=None, mean_mu=0.0, cov_mu=None, kern=kernel, theta=(1
 
 def posterior_mu_resident(db, new_dbs, timestamps, m_0, kern_0, kern_i, hp, pen_diag=0.1):
     """posterior_mu (MG:107-133) on the union of `timestamps` and the timestamps of EVERY new
-    individual in `new_dbs`, left on the device: returns the Engine holding mean / cov in HBM for
+    individual in `new_dbs`, left on the device: returns the NativeEngine holding mean / cov in HBM for
     `pred_gp_batched`. The hyper-posterior at a timestamp does not depend on which
     other timestamps the grid holds (a GP posterior is consistent under marginalisation), so this
     equals the reference's per-individual posterior_mu up to rounding."""
     _check_kern(kern_0, kern_i)
     extra = [np.asarray(timestamps, float).ravel()]
     extra += [np.asarray(nd["Timestamp"], float).ravel() for nd in new_dbs]
-    eng = Engine(Dataset(_as_db(db), extra_timestamps=np.concatenate(extra)), comm=_dist_comm())
+    eng = engine_for_job(Dataset(_as_db(db), extra_timestamps=np.concatenate(extra)))
     th0, thi = _hp_arrays(hp, eng.ds.ids)
     if isinstance(pen_diag, str):
         pen_diag = float(np.mean(thi[:, 2]))

@@ -1013,6 +1013,15 @@ int magma_logl_monitoring(magma_ctx* c, magma_dataset* d, const double* h_theta0
   return 0;
 }
 
+// ------------------------------------------------------------------ sums over individuals
+int magma_sum_fi(magma_ctx* c, magma_dataset* d, const double* h_theta_i, int theta_stride,
+                 int want_grad, double* h_out4) {
+  if (!c || !d || !h_theta_i || !h_out4) return fail(2, "sum_fi: NULL argument");
+  if (theta_stride != 0 && theta_stride != 3) return fail(2, "theta_stride must be 0 or 3");
+  if (int rc = set_device(c)) return rc;
+  return sum_fi(c, d, h_theta_i, theta_stride, want_grad ? 1 : 0, h_out4);
+}
+
 // ------------------------------------------------------------------ M-step (CF:397-437)
 int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
                  int common_hp, const double* opt4, double* h_theta0_out, double* h_theta_i_out) {

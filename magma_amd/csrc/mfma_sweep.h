@@ -35,6 +35,20 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
+// The callers scale the matrix by a power of two to a largest diagonal entry in [0.5, 1). R's
+// solve() (LU with partial pivoting, refused when rcond < eps; CF:133 then takes ginv) is what the
+// reference applies. An unpivoted sweep cannot tell a singular matrix by the sign of its pivots:
+// the late pivots of a matrix with singular values down to 1e-16 come out as POSITIVE rounding
+// noise of ~1e-10 of the scale (measured: sigma = 1e-9, n = 7, length scale e^3; LAPACK's dpotrf
+// does the same), and the inverse built from them is finite garbage of norm ~1e10. Two cheap
+// tests therefore send every matrix whose COMPUTED condition number is beyond ~1e9 to the slow
+// path, which applies R's own rule (LU, rcond, ginv): a pivot (= squared Cholesky diagonal =
+// Schur complement) below 2^-30 of the scale, or -- looked at by the callers after the sweep -- a
+// diagonal entry of the inverse at or above 2^30. Flagging a well-posed matrix costs time (the
+// slow path's LU answers it), never correctness.
+constexpr double SWEEP_PIVOT_MIN = 9.313225746154785e-10;  // 2^-30
+constexpr double SWEEP_INVDIAG_MAX = 1073741824.0;         // 2^30
+
 // A: NT x NT tiles (identity beyond the matrix). Pn: 64 NT doubles of LDS owned by this
 // wavefront. pm, pe accumulate det = pm * 2^pe over the pivots; info = index + 1 of the first
 // non-positive pivot (kept if already set). Single wavefront: LDS is in order per wavefront and
@@ -82,7 +96,7 @@ __device__ __forceinline__ void mfma_sweep(v4d (&A)[NT][NT], double* Pn, int l, 
     // not a positive finite number (what follows a bad pivot is garbage the caller discards: info)
     int bad = 0;
     auto fix = [&](double d, int k) {
-      const bool ok = (d > 0.0) && (d < 1.7e308);
+      const bool ok = (d > SWEEP_PIVOT_MIN) && (d < 1.7e308);
       bad = (!ok && bad == 0) ? k + 1 : bad;
       return d;
     };
@@ -256,7 +270,7 @@ __device__ __forceinline__ void mfma_sweep_lower(v4d (&A)[NT][NT], double* Pn, i
     hook(1);
     int bad = 0;
     auto fix = [&](double d, int k) {
-      const bool ok = (d > 0.0) && (d < 1.7e308);
+      const bool ok = (d > SWEEP_PIVOT_MIN) && (d < 1.7e308);
       bad = (!ok && bad == 0) ? k + 1 : bad;
       return d;
     };

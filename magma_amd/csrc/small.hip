@@ -46,6 +46,16 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 2^-e with d = m 2^e, 0.5 <= m < 1: scaling a matrix whose largest diagonal entry is d by it
+// brings the diagonal into (0, 1) without a single rounding (1 for a d that cannot be scaled; the
+// sweep then flags the matrix by itself).
+__device__ __forceinline__ double pow2_scale(double d) {
+  if (!(d > 0.0) || !(d < 1.7e308)) return 1.0;
+  int e;
+  (void)frexp(d, &e);
+  return ldexp(1.0, -e);
+}
+
 // Diagnostic build only (-DMAGMA_STAMPS): cycle shares of the segments of indiv_eval.
 #ifdef MAGMA_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -916,7 +926,8 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
     for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o));
     dmax = dm;
   }
-  const double sc = 1.0 / dmax;
+  // (a power of two: the scaling and its undoing are exact)
+  const double sc = pow2_scale(dmax);
 #pragma unroll
   for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -937,6 +948,22 @@ __device__ __forceinline__ void eval_factor(int lane, int n, int i, const SEPara
   mfma_sweep_lower<NT, NK>(A, Ks, l, g, pm, pe, info);
   FSTAMP(11);
   logdet = log(pm) + (double)pe * 0.69314718055994530941723212145818 - (double)n * log(sc);
+  {
+    // R's solve() refuses a matrix whose reciprocal condition number is below eps (CF:133 then
+    // takes ginv). The cheap stand-in here: the largest diagonal entry of the inverse of the
+    // scaled matrix (diagonal in [0.5, 1)) bounds its condition number from below; beyond 2^30
+    // the matrix goes to the slow path, which applies R's own rule (LU, rcond, ginv): see
+    // mfma_sweep.h, SWEEP_PIVOT_MIN.
+    double dinv = 0.0;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (16 * it + 4 * v < NMAX) dinv = fmax(dinv, (g + 4 * v == l) ? -A[it][it][v] : 0.0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dinv = fmax(dinv, __shfl_xor(dinv, o));
+    info = (info == 0 && !(dinv < SWEEP_INVDIAG_MAX)) ? n + 1 : info;
+  }
   info_res = info;
 
   // ---- 3. K^-1 = -A to LDS (whole tiles: columns beyond NMAX are exact zeros)
@@ -1684,7 +1711,7 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
     double factr, double pgtol, int maxit, double* __restrict__ theta_out,
     double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
     int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket,
-    int help_on) {
+    int help_on, int slow_all) {
   constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
   constexpr int RW = resident_waves<NMAX>();
   static_assert(NT <= 4, "four claim words per board");
@@ -1780,10 +1807,15 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
     const unsigned long long rs_t0 = __builtin_readcyclecounter();
 #endif
     lbfgsb_tell_device(st, f, g[0], g[1], g[2], factr, pgtol, maxit);
-    // a covariance the sweep flagged: the reference evaluates it through solve() / ginv()
-    // (CF:133); that evaluation lives in indiv_eval_slowpath_kernel, so this problem stops here
-    // with status 6 and the host solves it again through the lock-step route
-    if (info != 0 && info != -999) st->status = 6;
+    // A covariance the sweep flagged: the reference evaluates it through solve() / ginv()
+    // (CF:133); that evaluation lives in indiv_eval_slowpath_kernel. At the START point the
+    // problem stops with status 6 and the host solves it through the lock-step route, whose
+    // evaluations take that path (the optimiser cannot start from a non-finite value). At a
+    // trial point of a line search the non-finite value makes the search bisect towards its
+    // best point (lbfgsb_core.h) -- unless slow_all asks for status 6 there too (option
+    // "resident_slow_path": the reference's value at every flagged point, at the price of
+    // solving those problems twice; see DESIGN.md for the measured cost).
+    if (info != 0 && info != -999 && (slow_all != 0 || st->nfev == 1)) st->status = 6;
 #ifdef MAGMA_RES_STAMPS
     if (helped && lane == 0) atomicAdd(&g_res_stamps[12], __builtin_readcyclecounter() - rs_t0);  // tell
     if (helped && lane == 0) atomicAdd(&g_res_stamps[13], rs_t0 - rs_e0);  // start -> tell
@@ -1955,7 +1987,7 @@ __device__ __forceinline__ void pred_inverse_to_lds(int lane, int n, const SEPar
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o));
   // (a non-positive diagonal cannot be scaled; the sweep then flags the matrix by itself)
-  const double sc = (dm > 0.0 && dm < 1.7e308) ? 1.0 / dm : 1.0;
+  const double sc = pow2_scale(dm);
 #pragma unroll
   for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -1973,6 +2005,17 @@ __device__ __forceinline__ void pred_inverse_to_lds(int lane, int n, const SEPar
   info = 0;
   wave_sync();
   mfma_sweep<NT, NK>(A, Ks, l, g, pm, pe, info);
+  {  // (see eval_factor: a stand-in for the rcond test of R's solve())
+    double dinv = 0.0;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (16 * it + 4 * v < NMAX) dinv = fmax(dinv, (g + 4 * v == l) ? -A[it][it][v] : 0.0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dinv = fmax(dinv, __shfl_xor(dinv, o));
+    info = (info == 0 && !(dinv < SWEEP_INVDIAG_MAX)) ? n + 1 : info;
+  }
 #pragma unroll
   for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -2251,7 +2294,11 @@ void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v
 void set_resident_max_workgroups_thread(int v) { t_resident_max_wgs = v; }
 // Idle wavefronts help the running ones of their workgroup (default on; same results either way).
 static std::atomic<int> g_resident_help{1};
-void set_resident_help(int v) { g_resident_help.store(v & 3); }  // bit 1: every compute unit even for few individuals (diagnostic)
+void set_resident_help(int v) { g_resident_help.store(v & 3); }
+// 1: a flagged trial point inside a line search also stops the problem with status 6 (default 0:
+// only a flagged start point does; a flagged trial point bisects)
+static std::atomic<int> g_resident_slow{0};
+void set_resident_slow_path(int v) { g_resident_slow.store(v ? 1 : 0); }  // bit 1: every compute unit even for few individuals (diagnostic)
 int resident_diag_read(unsigned long long* h24) {
 #ifdef MAGMA_RES_STAMPS
   return check_hip(hipMemcpyFromSymbol(h24, HIP_SYMBOL(g_res_stamps), 16 * sizeof(unsigned long long)),
@@ -2326,7 +2373,8 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
   if (cap > 0 && grid > cap) grid = cap;
   hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RW), dyn, st, M, order, off,
                      t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out,
-                     fx0_out, iters, nfev, status, ticket, g_resident_help.load(std::memory_order_relaxed) & 1);
+                     fx0_out, iters, nfev, status, ticket, g_resident_help.load(std::memory_order_relaxed) & 1,
+                     g_resident_slow.load(std::memory_order_relaxed));
   return check_hip(hipGetLastError(), "indiv_mstep");
 }
 

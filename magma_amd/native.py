@@ -46,6 +46,39 @@ def device_tensor(ptr, n):
     return torch.as_tensor(d, device="cuda")
 
 
+def dist_allreduce(dist):
+    """All-reduce callback for the library's callback communicator over an initialised
+    torch.distributed group: RCCL ("nccl") sums the device buffer in place; any other backend
+    (gloo: tests, rehearsals) stages it through the host."""
+    import torch
+    on_device = dist.get_backend() == "nccl"
+
+    def allreduce(ptr, count):
+        tens = device_tensor(ptr, count)
+        if on_device:
+            torch.cuda.synchronize()
+            dist.all_reduce(tens)
+        else:
+            host = tens.cpu()
+            dist.all_reduce(host)
+            tens.copy_(host)
+        torch.cuda.synchronize()
+    return allreduce
+
+
+def engine_for_job(ds, device=None):
+    """This process's NativeEngine on `ds`: alone, or rank r of an initialised torch.distributed
+    job (the library's callback communicator over that group; contiguous shards of individuals)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return NativeEngine(ds, rank=dist.get_rank(), world=dist.get_world_size(),
+                                allreduce=dist_allreduce(dist), device=device)
+    except ImportError:  # pragma: no cover
+        pass
+    return NativeEngine(ds, device=device)
+
+
 class NativeEngine:
     """One rank of the native driver: a context (device, streams, communicator) and this rank's
     shard of `ds` (magma_amd.engine.Dataset) resident on the device.
@@ -172,6 +205,14 @@ class NativeEngine:
         out = C.c_double(0.0)
         _lib.call("magma_logl_monitoring", self._ctx, self._ds, _hp(th0), _hp(th), stride, C.byref(out))
         return out.value
+
+    def sum_fi(self, theta_i, want_grad=False):
+        """Sum over ALL individuals of logL_GP_mod (and of gr_GP_mod): CF:203-234, 334-368 with one
+        triple, CF:254-261 with [M, 3]. Returns (f, g[3])."""
+        th, stride = self._theta_i(theta_i)
+        out = np.zeros(4)
+        _lib.call("magma_sum_fi", self._ctx, self._ds, _hp(th), stride, int(bool(want_grad)), _hp(out))
+        return float(out[0]), out[1:].copy()
 
     def em_iteration(self, theta0, theta_i, m0, common_hp, opt_kw=None):
         th0, th = _f64(theta0), _f64(theta_i)

@@ -1,6 +1,13 @@
-"""Multi-rank host logic under gloo (world_size 2) on the CPU: Engine shards individuals,
-all-reduces the partial precision / weighted mean, sums objective pieces and gathers the
-per-individual hyper-parameters. A test-only oracle backend stands in for the HIP backend."""
+"""The sharding + reduction PATTERN of the multi-rank EM under gloo, world_size 2, on
+the CPU: contiguous shards of individuals, all-reduced partial precision / weighted mean, summed
+objective pieces, gathered per-individual hyper-parameters.
+
+What this covers and what it does not: no GPU here, so the math is the oracle's (tests/cpu_backend)
+and the EM logic is the Python MIRROR of the driver (tests/host_mirror.py) -- test infrastructure,
+not the product. The product's multi-rank path (csrc/driver.hip behind NativeEngine) is covered on
+the GPU: two gloo PROCESSES sharing one GPU through the library's callback communicator
+(tests/test_gpu_dist_native.py), several ranks as threads (tests/test_gpu_native.py), and RCCL with
+one rank; more than one RCCL rank needs more than one GPU and is the driver's SCALE run."""
 import os
 import sys
 import numpy as np
@@ -22,7 +29,8 @@ def _run(rank, world, port, common, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch.distributed as dist
-    from magma_amd.engine import Dataset, Engine, Comm
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine, Comm
     from cpu_backend import OracleBackend
     comm = None
     if world > 1:

@@ -44,7 +44,13 @@ def c4():
         new_dbs.append({"Timestamp": t[:nb], "Output": 0.5 * t[:nb] + rng.normal(size=nb)})
         tss.append(t[nb:])
     pen, m0 = 0.9, 0.3
-    eng = m.posterior_mu_resident(db, new_dbs, grid, m0, m.kernel_mu, m.kernel, hp, pen_diag=pen)
+    # kernel-level bindings (HipBackend) under the test-side mirror of the driver: these tests poke
+    # at the resident buffers between the kernel-level calls
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
+    extra = np.concatenate([grid] + [nd["Timestamp"] for nd in new_dbs])
+    eng = Engine(Dataset(db, extra_timestamps=extra))
+    assert eng.e_step(hp["theta_0"], thi, pen, m0) == 0
     assert eng.ds.N == N and eng.be.Np == 8000
     return dict(torch=torch, m=m, db=db, a=a, hp=hp, thi=thi, eng=eng, new_dbs=new_dbs, tss=tss,
                 pen=pen, m0=m0, grid=grid)
@@ -135,15 +141,34 @@ def test_c4_per_individual_objectives_and_prediction_match_oracle(c4):
         assert np.abs(got[b]["Var"] - exp["Var"]).max() < 1e-8 * max(1.0, np.abs(exp["Var"]).max()), b
 
 
-def test_c4_em_iteration_runs_and_increases_the_likelihood(c4):
-    """One full EM iteration at C4 size through the default routes (resident M-step, theta_0 chain
-    on the side stream): finite, and logL(new hp) >= logL(hp) as EM guarantees (MG:54-64)."""
-    from magma_amd.engine import Dataset, Engine
+def test_c4_native_posterior_and_em_iteration(c4):
+    """The product path at C4 size: posterior_mu_resident (one native E-step on the 8,000-point
+    grid) gives the kernel-level route's hyper-posterior, its batched prediction the same numbers,
+    and one full EM iteration through the driver's default routes (resident M-step, theta_0 chain
+    on the side stream) is finite with logL(new hp) >= logL(hp) as EM guarantees (MG:54-64)."""
+    m = c4["m"]
+    from magma_amd.native import NativeEngine
+    nat = m.posterior_mu_resident(c4["db"], c4["new_dbs"], c4["grid"], c4["m0"], m.kernel_mu, m.kernel,
+                                  c4["hp"], pen_diag=c4["pen"])
+    assert isinstance(nat, NativeEngine) and nat.ds.N == N
+    ref_mean = c4["eng"].be.get_mean()
+    assert np.abs(nat.get_mean() - ref_mean).max() < 1e-9 * np.abs(ref_mean).max()
+    B = len(c4["new_dbs"])
+    rng = np.random.default_rng(8)
+    thetas = np.column_stack([rng.uniform(0, 2, B), rng.uniform(0, 1, B)])
+    sigmas = rng.uniform(0.2, 1.0, B)
+    got = m.pred_gp_batched(nat, c4["new_dbs"], c4["tss"], thetas, sigmas)
+    ref = m.pred_gp_batched(c4["eng"], c4["new_dbs"], c4["tss"], thetas, sigmas)
+    for b in range(B):
+        assert np.abs(got[b]["Mean"] - ref[b]["Mean"]).max() < 1e-9 * max(1.0, np.abs(ref[b]["Mean"]).max())
+        assert np.abs(got[b]["Var"] - ref[b]["Var"]).max() < 1e-9 * max(1.0, np.abs(ref[b]["Var"]).max())
+    nat.close()
     a = c4["a"]
-    ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
-    eng = Engine(ds)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    eng = NativeEngine(ds)
     th0 = np.array([1.0, 1.0])
     thi = np.tile([1.0, 1.0, 0.2], (M, 1))
     n0, ni, l_old, l_new = eng.em_iteration(th0, thi, 0.0, False, {"maxit": 5})
     assert np.all(np.isfinite(n0)) and np.all(np.isfinite(ni))
     assert np.isfinite(l_old) and l_new > l_old
+    eng.close()

@@ -58,7 +58,7 @@ def _run_ranks(ds, world, fn):
     """fn(engine) on `world` engines over the shards of ds, one thread per rank; returns the
     per-rank results (exceptions re-raised)."""
     import torch
-    from magma_amd.engine import Engine
+    from host_mirror import Engine
     shared = ThreadComm.Shared(world)
     out, errs = [None] * world, []
 
@@ -110,7 +110,8 @@ def c5():
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     from magma_amd.synth import simu_arrays
     a = simu_arrays(100000, 40, 2000, seed=1005)
     ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])

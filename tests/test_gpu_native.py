@@ -72,7 +72,8 @@ def test_native_em_iteration_equals_python_engine_and_oracle(m, sizes, common):
     thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1))
     if not common:  # (with common HPs `training` keeps every row equal, MG:26-27, CF:420)
         thi = thi + rng.uniform(-0.3, 0.3, size=(ds.M, 3))
-    nat, py = NativeEngine(ds), m.Engine(ds)
+    from host_mirror import Engine
+    nat, py = NativeEngine(ds), Engine(ds)
     pen = float(np.mean(thi[:, 2]))
     assert nat.e_step(th0, thi, pen, 0.4) == 0 and py.e_step(th0, thi, pen, 0.4) == 0
     c_n, c_p = nat.get_cov(), py.be.get_cov()
@@ -110,7 +111,8 @@ def test_native_training_individual_hp_equals_python_engine(m):
     from magma_amd.native import NativeEngine
     _, _, train = dataset("data_FF", 1)
     ds = m.Dataset(train)
-    nat, py = NativeEngine(ds), m.Engine(ds)
+    from host_mirror import Engine
+    nat, py = NativeEngine(ds), Engine(ds)
     t_n, t_p = [], []
     a = nat.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_n)
     b = py.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_p)
@@ -484,7 +486,7 @@ def test_individuals_with_more_than_64_observations(m):
     for i in ds.ids:
         assert np.abs(got[i][1] - ref_inv[i][1]).max() < 1e-9 * np.abs(ref_inv[i][1]).max(), i
     with pytest.raises(ValueError, match="NativeEngine"):
-        m.Engine(ds)
+        m.HipBackend(ds, 0, ds.M)
 
 
 def test_common_times_common_hp_inverts_once(m):
@@ -549,8 +551,9 @@ def test_failed_estep_factorisation_is_an_error_not_a_silent_nan(m):
     assert info != 0 and np.isnan(nat.last_f0)
     with pytest.raises(np.linalg.LinAlgError):
         nat.em_iteration(th0, thi, 0.0, False)
+    from host_mirror import Engine
     with pytest.raises(np.linalg.LinAlgError):
-        m.Engine(ds).em_iteration(th0, thi, 0.0, False)
+        Engine(ds).em_iteration(th0, thi, 0.0, False)
     # the engine is still usable afterwards
     assert nat.e_step(np.array([1.0, 1.0]), thi, 0.2, 0.0) == 0 and np.isfinite(nat.last_f0)
     nat.close()

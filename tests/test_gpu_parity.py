@@ -280,7 +280,8 @@ def test_em_iteration_shortcuts_equal_explicit_monitoring(gpu):
     """The engine takes logL_monitoring(hp) from by-products (K_0^-1 of the E-step, the
     optimisers' first evaluations) and reuses K_0^-1 between monitoring(new hp) and the next
     E-step: both must equal the explicit computations and the oracle."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(21)
     db = _ragged_db(rng, [30, 12, 40, 7, 25, 33])
     ds = Dataset(db)
@@ -311,7 +312,8 @@ def test_em_iteration_shortcuts_equal_explicit_monitoring(gpu):
 def test_native_mstep_loop_equals_python_driven_loop(gpu):
     """magma_indiv_mstep (C++ round loop, compact ask/tell) against minimize_batch driving
     magma_indiv_eval from Python: same optimiser, same evaluations -> identical results."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(23)
     db = _ragged_db(rng, [5, 30, 17, 50, 42, 30, 8, 64])
     ids = orc.unique_in_order(db["ID"])
@@ -340,7 +342,8 @@ def test_native_mstep_loop_equals_python_driven_loop(gpu):
 def test_resident_mstep_equals_lock_step_mstep(gpu):
     """magma_indiv_mstep_resident (L-BFGS-B stepped inside the evaluating wavefronts) against the
     host-driven lock-step loop: same optimiser source, same evaluation code -> same iterates."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(29)
     db = _ragged_db(rng, [5, 30, 17, 50, 42, 30, 8, 64, 1, 2])
     ids = orc.unique_in_order(db["ID"])
@@ -367,7 +370,8 @@ def test_resident_mstep_helper_wavefronts_do_not_change_results(gpu, sizes):
     launched, so that most workgroups consist of helpers only). Block sums are added in block
     order whoever computed them: every mode gives the bits of the lock-step loop, and no workgroup
     gave up on a wait (magma_debug_resident_diag word 0)."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     _lib = gpu["_lib"]
     rng = np.random.default_rng(31)
     db = _ragged_db(rng, sizes)
@@ -414,7 +418,8 @@ def test_results_do_not_depend_on_stale_lds(gpu):
         poison()
         fn(gpu, *args)
     # the f-only evaluation on its own, many times over (the kernel that showed it)
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(31)
     db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 50, 1])
     ds = Dataset(db)
@@ -512,7 +517,8 @@ def test_em_iteration_is_bitwise_repeatable_and_routes_agree(gpu):
     repeatable bit for bit; the atomic route agrees with it to rounding, and both with the
     oracle (flagged individuals included: they contribute through the slow path, as
     tryCatch(solve, ginv) does at CF:161)."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(43)
     db = _ragged_db(rng, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50])
     ds = Dataset(db)

@@ -29,7 +29,8 @@ def m():
 
 
 def _setup(m, seed, sizes, th0=(0.9, 0.7), pen=0.4):
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(seed)
     db = _db(rng, sizes)
     ds = Dataset(db)

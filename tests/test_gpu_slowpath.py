@@ -71,7 +71,8 @@ def test_kern_to_inv_of_singular_matrices_matches_solve_or_ginv(m):
 def test_e_step_with_singular_individuals_matches_oracle(m, route):
     """CF:383-391 with three individuals whose K_i is singular: the reference adds ginv(K_i) to
     the precision; so does the HIP path (both E-step routes), instead of dropping them."""
-    from magma_amd.engine import Dataset, Engine
+    from magma_amd.engine import Dataset
+    from host_mirror import Engine
     rng = np.random.default_rng(1)
     db = _db(rng, [30, 12, 40, 7, 25, 33, 2, 50])
     ds = Dataset(db)

@@ -95,7 +95,7 @@ def test_individual_hp_em_trajectory_equals_oracle_with_shared_optimiser(m, d):
     print(f"FF dataset {d}, per iteration from the oracle's hyper-parameters: " +
           ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     assert worst["ll_old"] < 1e-10 and worst["th0"] < 1e-9, worst
-    assert worst["ll_new"] < 1e-6 and worst["thi"] < 1e-4 and worst["f"] < 1e-8, worst
+    assert worst["ll_new"] < 1e-6 and worst["thi"] < 5e-4 and worst["f"] < 1e-8, worst
     # (b) the whole fit as one library call
     t_n = []
     th0, thi, cv = eng.training(0.0, [1.0, 1.0], [1.0, 1.0, 0.2], common_hp=False, trace=t_n)
