@@ -394,13 +394,17 @@ int magma_spd_inverse_static(int N, double* A, double* d_logdet, int* d_info, vo
   return launch_spd_inverse(magma_pad(N), A, d_logdet, d_info, ws, S(stream));
 }
 
-int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
-                       const double* m0, double* P, double* w, double* mean_out, void* work,
-                       int reuse_k0inv, double* h_f0, int* h_info, void* stream) {
+}  // extern "C"
+// The dense part of the E-step, queued on st without waiting: h_pin3 (pinned host memory, 3
+// doubles) receives f0 in [0] and the info words of K_0 and of the precision as two ints in [1]
+// once st has passed this point (estep_finish_read decodes them).
+namespace magma {
+int estep_finish_launch(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                        const double* m0, double* P, double* w, double* mean_out, void* work,
+                        int reuse_k0inv, int want_f0, double* h_pin3, hipStream_t st) {
   if (N < 1) return fail(2, "N must be >= 1");
   const int Np = magma_pad(N);
   const size_t n2 = (size_t)Np * Np;
-  hipStream_t st = S(stream);
   Work wk(work, Np);
   int rc;
   if (!reuse_k0inv) {
@@ -419,21 +423,40 @@ int magma_estep_finish(int N, const double* grid, double theta1, double theta2, 
     if ((rc = launch_spd_inverse(Np, P, wk.scal + 5, wk.iinfo + 1, wk.inv, st))) return rc;
   }
   if ((rc = launch_symv(Np, P, w, mean_out, st))) return rc;
-  if (h_f0) {
+  if (want_f0) {
     // logL_GP_mod(theta_0; db = new mean, new_cov = new cov, pen_diag) from the K_0^-1 that is
     // still in the workspace: z'K_0^-1 z, log|K_0| and sum(K_0^-1 o cov) -- no factorisation.
     if ((rc = launch_theta0_vec(N, Np, wk.A0, P, mean_out, m0, wk.alpha, wk.vpart, st))) return rc;
     if ((rc = launch_theta0_finish2(N, Np, wk.scal + 0, wk.iinfo + 0, wk.vpart, wk.partials, 0,
                                     wk.scal + 8, st)))
       return rc;
-    MAGMA_CHECK_HIP(hipMemcpyAsync(h_f0, wk.scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  int hinfo[2] = {0, 0};
-  MAGMA_CHECK_HIP(hipMemcpyAsync(hinfo, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
-  if (h_info) *h_info = hinfo[0] ? hinfo[0] : (hinfo[1] ? -hinfo[1] : 0);
+  // h_pin3[0] = f0; the two info words as ints in h_pin3[1]
+  if (want_f0) MAGMA_CHECK_HIP(hipMemcpyAsync(h_pin3, wk.scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipMemcpyAsync(h_pin3 + 1, wk.iinfo, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  return 0;
+}
+void estep_finish_read(const double* h_pin3, double* h_f0, int* h_info) {
+  const int* ii = reinterpret_cast<const int*>(h_pin3 + 1);
+  const int i0 = ii[0], i1 = ii[1];
+  if (h_info) *h_info = i0 ? i0 : (i1 ? -i1 : 0);
   // either factorisation failed: mean / cov are garbage, and so is an objective value built on them
-  if (h_f0 && (hinfo[0] || hinfo[1])) *h_f0 = __builtin_nan("");
+  if (h_f0) *h_f0 = (i0 || i1) ? __builtin_nan("") : h_pin3[0];
+}
+}  // namespace magma
+extern "C" {
+
+int magma_estep_finish(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                       const double* m0, double* P, double* w, double* mean_out, void* work,
+                       int reuse_k0inv, double* h_f0, int* h_info, void* stream) {
+  hipStream_t st = S(stream);
+  thread_local double* pin = nullptr;
+  if (!pin) MAGMA_CHECK_HIP(hipHostMalloc((void**)&pin, 3 * sizeof(double), hipHostMallocDefault));
+  if (int rc = estep_finish_launch(N, grid, theta1, theta2, pen_diag, m0, P, w, mean_out, work,
+                                   reuse_k0inv, h_f0 != nullptr, pin, st))
+    return rc;
+  MAGMA_CHECK_HIP(hipStreamSynchronize(st));
+  estep_finish_read(pin, h_f0, h_info);
   return 0;
 }
 

@@ -43,6 +43,12 @@ int theta0_mstep_impl(int N, const double* grid, const double* h_theta0, double 
 // (N^3) instead of a full product (2 N^3) and the lower tiles (N^3).
 // After magma_estep_finish on `work`: V <- U^T, U = L^-T as left in the workspace by the inverse.
 int estep_cov_factor(int N, void* work, double* V, hipStream_t st);
+// magma_estep_finish without the wait: everything queued on st, (f0, info words) copied to the
+// pinned h_pin3 (3 doubles) behind it; estep_finish_read decodes them after st was synchronised.
+int estep_finish_launch(int N, const double* grid, double theta1, double theta2, double pen_diag,
+                        const double* m0, double* P, double* w, double* mean_out, void* work,
+                        int reuse_k0inv, int want_f0, double* h_pin3, hipStream_t st);
+void estep_finish_read(const double* h_pin3, double* h_f0, int* h_info);
 int dag_diag(int N, void* work, int* h_two);
 
 // logL_GP_mod + gr_GP_mod (CF:181-201, 304-332) of ONE individual with more observations than a

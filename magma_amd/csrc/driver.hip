@@ -163,6 +163,7 @@ struct magma_dataset {
   bool cpack_early = false;  // set by magma_em_iteration around its E-step
   bool theta_from_estep = false;  // d->theta holds the theta_i rows magma_em_iteration's E-step uploaded
   std::vector<double> h_m0_last;  // last prior mean uploaded (set_m0)
+  double* h_fin = nullptr;        // pinned: (f0, info words) of the E-step's dense part
   double* h_mon = nullptr;        // pinned: (f, g1, g2, info) of a deferred theta_0 evaluation
   int* h_flag = nullptr;          // pinned: per-individual info of the last E-step, counted lazily
   bool flag_pending = false;
@@ -188,6 +189,7 @@ struct magma_dataset {
     if (pre0_ev) (void)hipEventDestroy(pre0_ev);
     if (h_rres) (void)hipHostFree(h_rres);
     if (h_mon) (void)hipHostFree(h_mon);
+    if (h_fin) (void)hipHostFree(h_fin);
     if (h_flag) (void)hipHostFree(h_flag);
   }
   DevBuf ddS, ddC, ddy, ddoff, ddf, ddg, ddinfo;
@@ -962,33 +964,35 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                     d->a0_key[2] == pen_diag;
   int info = 0;
   double f0 = 0.0;
-  if ((rc = magma_estep_finish(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_diag,
-                               d->m0.as<double>(), d->P.as<double>(), d->w.as<double>(),
-                               d->mean.as<double>(), d->work.p, reuse, &f0, &info, st)))
+  if (!d->h_fin) MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_fin, 3 * sizeof(double), hipHostMallocDefault));
+  if ((rc = estep_finish_launch(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_diag,
+                                d->m0.as<double>(), d->P.as<double>(), d->w.as<double>(),
+                                d->mean.as<double>(), d->work.p, reuse, 1, d->h_fin, st)))
     return rc;
+  // Queued behind the dense part BEFORE the host waits for it (a failed factorisation leaves
+  // garbage in both, marked invalid below): inside an EM iteration with individual
+  // hyper-parameters the M-step's first need is the packed cov blocks; and the factor of cov for
+  // the theta_0 gradient.
+  const bool want_fac = (!c->has_comm() || !theta0_shard_enabled()) && d->covfac.p && covfac_enabled();
+  if (d->cpack_early && (rc = ensure_cpack(d, st))) return rc;
+  if (want_fac && (rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
+  if (d->M > 0) {  // individuals whose K_i was not positive definite (they took the solve() / ginv() slow path)
+    if (!d->h_flag)
+      MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_flag, sizeof(int) * (size_t)d->M, hipHostMallocDefault));
+    MAGMA_CHECK_HIP(hipMemcpyAsync(d->h_flag, d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
+    d->flag_pending = true;
+  }
+  if ((rc = sync(st))) return rc;
+  estep_finish_read(d->h_fin, &f0, &info);
   HT("e: finish (sync)");
   d->a0_valid = (info == 0);
   d->a0_key[0] = h_theta0[0];
   d->a0_key[1] = h_theta0[1];
   d->a0_key[2] = pen_diag;
   d->last_f0 = f0;
-  // inside an EM iteration with individual hyper-parameters the M-step's first need is the packed
-  // cov blocks: the gather is queued here, ahead of the small kernels and host round trips below
-  if (info == 0 && d->cpack_early)
-    if ((rc = ensure_cpack(d, st))) return rc;
-  d->covfac_ok = false;
-  if (info == 0 && (!c->has_comm() || !theta0_shard_enabled()) && d->covfac.p && covfac_enabled()) {
-    if ((rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
-    d->covfac_ok = true;
-  }
-  if (d->M > 0) {  // individuals whose K_i was not positive definite (they took the solve() / ginv() slow path)
-    if (!d->h_flag)
-      MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_flag, sizeof(int) * (size_t)d->M, hipHostMallocDefault));
-    MAGMA_CHECK_HIP(hipMemcpyAsync(d->h_flag, d->info.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
-    d->flag_pending = true;
-    // (inside an EM iteration the M-step's first synchronisation of this stream counts them)
-    if (!d->cpack_early && (rc = count_flagged(d, st))) return rc;
-  }
+  if (info != 0) d->cpack_ok = false;
+  d->covfac_ok = (info == 0) && want_fac;
+  if (d->M > 0 && (rc = count_flagged(d, st, false))) return rc;  // (copied before the wait above)
   if (h_info) *h_info = info;
   if (h_f0) *h_f0 = f0;
   HT("e: factor + flagged (sync)");
@@ -1067,13 +1071,22 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   HT("m: entry");
   const bool overlap = !common_hp || !c->has_comm();
   std::thread th0;
+  bool started0 = false;
+  auto start0 = [&]() {  // (idempotent)
+    if (overlap && !started0) {
+      started0 = true;
+      th0 = std::thread(run0);
+    }
+  };
   if (overlap) {
     // both streams read the hyper-posterior the E-step left on the main stream
     if (int rc = sync(st)) return rc;
     if (int rc = count_flagged(d, st, false)) return rc;
     const bool split = !common_hp && c->reserve_cus > 0 && M > 0;
     set_resident_max_workgroups_thread(split ? std::max(1, c->ncu - c->reserve_cus) : -1);
-    th0 = std::thread(run0);
+    // with individual hyper-parameters the resident kernel is launched first (a few microseconds)
+    // and the helper thread -- tens of microseconds to create -- right behind it
+    if (common_hp || M == 0) start0();
   }
   bool joined = false;
   auto join0 = [&]() -> int {
@@ -1137,6 +1150,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M),
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M) + M, st)))
           break;
+        start0();
         // x, f, f(x0) and the evaluation counts sit in one block: one copy into pinned memory
         if (!d->h_rres &&
             (rc = check_hip(hipHostMalloc(&d->h_rres, sizeof(double) * 6 * (size_t)M, hipHostMallocDefault),
@@ -1205,6 +1219,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
         d->stats.indiv_rounds += mx;
       } while (false);
     }
+    start0();  // (M == 0, or an error before the launch: the theta_0 problem is still solved)
     // results by local row; individuals on the dense route are optimised one after the other by
     // the host-side L-BFGS-B around the dense evaluation (CF:423-431 for n_i > 64)
     std::vector<double> loc((size_t)(3 * std::max<int64_t>(d->Mloc, 1)));
