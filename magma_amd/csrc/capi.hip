@@ -676,6 +676,10 @@ int magma_set_option(const char* name, long value) {
     set_resident_slow_path((int)value);
     return 0;
   }
+  if (std::string(name) == "panel_blocks") {  // launch-per-step inverse: panels per super-step
+    set_panel_blocks((int)value);
+    return 0;
+  }
   if (std::string(name) == "dag_workgroups") {
     if (value < 0 || value > 4096) return fail(2, "dag_workgroups must be in 0..4096");
     set_dag_workgroups((int)value);

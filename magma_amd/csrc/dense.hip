@@ -11,6 +11,8 @@
 // Replaces (Computing_functions.R = CF): kern_to_cov/kern_to_inv vector branch CF:66-81,
 // 121-138; solve(new_inv) CF:387; logL_GP_mod / gr_GP_mod at theta_0 (CF:181-201, 304-332).
 #include "common.h"
+#include <atomic>
+#include <algorithm>
 #include "kernels.h"
 #include "mfma_sweep.h"
 #include "dense_tile.h"
@@ -334,11 +336,19 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(double* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------ trailing update
-// A_ij -= L_ik L_jk^T for k < j <= i. The workgroup of tile (k+1, k+1) -- block 0, dispatched
-// first -- goes on to factor that tile and emit X / U of step k+1 (potrf_diag_block) while the
-// other workgroups finish the update: the serial part of the next step hides behind this one.
+// A_ij -= sum over the kc finished panels k .. k + kc - 1 of L_i. L_j.^T (the panels are adjacent
+// block columns: one product with K = 64 kc), for the target tiles
+//   col_only = 0: j0 <= j <= i  (everything right of the panels; j0 = k + kc),
+//   col_only = 1: j = j0 <= i   (block column j0 only: the next panel of a super-step).
+// A rank-64 kc update reads and writes each target tile once per kc panels instead of once per
+// panel: at N = 8,000 the rank-64 form spends its time moving the trailing matrix (4 flops per
+// byte), which is what the super-steps of launch_spd_inverse cut. The workgroup of tile (j0, j0)
+// -- block 0, dispatched first -- goes on to factor that tile and emit X / U of step j0
+// (potrf_diag_block) while the other workgroups finish the update: the serial part of the next
+// step hides behind this one.
 __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A, int64_t ld,
-                                                          int k, int nt, double* __restrict__ X,
+                                                          int k, int kc, int j0, int col_only,
+                                                          double* __restrict__ X,
                                                           double* __restrict__ U,
                                                           double* __restrict__ logdet,
                                                           int* __restrict__ info) {
@@ -357,17 +367,20 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
   double* As = Ls;
   double* Bs = As + 16 * TLD;
 #endif
-  // lower-triangle tile index -> (bi, bj), bj <= bi; tile 0 = (0, 0) = block (k+1, k+1)
+  // lower-triangle tile index -> (bi, bj), bj <= bi; tile 0 = (0, 0) = block (j0, j0)
   const int p = blockIdx.x;
-  int bi = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-  while (bi * (bi + 1) / 2 > p) --bi;
-  while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
-  const int bj = p - bi * (bi + 1) / 2;
-  const int i = k + 1 + bi, j = k + 1 + bj;
+  int bi = p, bj = 0;
+  if (!col_only) {
+    bi = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > p) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
+    bj = p - bi * (bi + 1) / 2;
+  }
+  const int i = j0 + bi, j = j0 + bj;
   TileAcc acc;
   tile_zero(acc);
   tile_gemm_nt(A + (int64_t)i * NB + (int64_t)k * NB * ld, ld,
-               A + (int64_t)j * NB + (int64_t)k * NB * ld, ld, 4, acc, As, Bs);
+               A + (int64_t)j * NB + (int64_t)k * NB * ld, ld, 4 * kc, acc, As, Bs);
   double* C = A + (int64_t)i * NB + (int64_t)j * NB * ld;
   if (p != 0) {
     tile_foreach(acc, [&](int m, int n, double v) { C[m + (int64_t)n * ld] -= v; });
@@ -385,9 +398,9 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ A
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = Ls[row * 65 + 4 * q + ty];
   __syncthreads();
-  potrf_diag_block(d, Ls, colbuf, piv, invd, k + 1, ld, X, U, logdet, info);
+  potrf_diag_block(d, Ls, colbuf, piv, invd, j0, ld, X, U, logdet, info);
 #else
-  potrf_diag_block_mfma(Ls, Pn, Xch, k + 1, ld, X, U, logdet, info);
+  potrf_diag_block_mfma(Ls, Pn, Xch, j0, ld, X, U, logdet, info);
 #endif
 }
 
@@ -912,6 +925,10 @@ int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2
 
 size_t spd_inverse_workspace_doubles(int Np) { return 3 * (size_t)Np * Np; }
 
+// Panels per super-step of the launch-per-step inverse (N > 4,096); 1 = the plain right-looking form.
+static std::atomic<int> g_panel_blocks{4};
+void set_panel_blocks(int v) { g_panel_blocks.store(v < 1 ? 1 : (v > 16 ? 16 : v)); }
+
 int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* work,
                        hipStream_t st) {
   if (spd_inverse_dag_supported(Np)) return launch_spd_inverse_dag(Np, A, logdet, info, work, st);
@@ -923,11 +940,26 @@ int launch_spd_inverse(int Np, double* A, double* logdet, int* info, double* wor
   MAGMA_CHECK_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
   MAGMA_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
   hipLaunchKernelGGL(potrf_diag0_kernel, dim3(1), dim3(256), 0, st, A, ld, X, U, logdet, info);
-  for (int k = 0; k + 1 < nt; ++k) {
-    const int rem = nt - k - 1;
-    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(rem), dim3(256), 0, st, A, ld, k, X);
-    hipLaunchKernelGGL(syrk_update_kernel, dim3(rem * (rem + 1) / 2), dim3(256), 0, st, A, ld, k, nt,
-                       X, U, logdet, info);
+  // Super-steps of `pw` panels (block columns): inside one, each new panel's block column is
+  // brought up to date with the panels before it (left-looking, rank 64 c) and factored; the
+  // matrix right of the super-step is then updated once with all of them (rank 64 pw).
+  const int pw = g_panel_blocks.load(std::memory_order_relaxed);
+  for (int k0 = 0; k0 + 1 < nt; k0 += pw) {
+    const int w = std::min(pw, nt - k0);
+    for (int c = 0; c < w; ++c) {
+      const int col = k0 + c;
+      if (col + 1 >= nt) break;
+      hipLaunchKernelGGL(trsm_gemm_kernel, dim3(nt - col - 1), dim3(256), 0, st, A, ld, col, X);
+      if (c + 1 < w)  // block column col + 1: panels k0 .. col
+        hipLaunchKernelGGL(syrk_update_kernel, dim3(nt - col - 1), dim3(256), 0, st, A, ld, k0, c + 1,
+                           col + 1, 1, X, U, logdet, info);
+    }
+    const int j0 = k0 + w;
+    if (j0 < nt) {
+      const int rem = nt - j0;
+      hipLaunchKernelGGL(syrk_update_kernel, dim3(rem * (rem + 1) / 2), dim3(256), 0, st, A, ld, k0, w, j0,
+                         0, X, U, logdet, info);
+    }
   }
   int depth = 0;
   while ((1 << depth) < nt) ++depth;

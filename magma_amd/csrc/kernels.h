@@ -27,6 +27,7 @@ int launch_indiv_mstep(int M, int nmax, const int* order, const int64_t* off, co
 void set_resident_max_workgroups(int v);         // process default (option "resident_max_workgroups")
 void set_resident_max_workgroups_thread(int v);  // the calling thread's launches; -1 = the default
 void set_resident_help(int v);
+void set_panel_blocks(int v);
 void set_resident_slow_path(int v);
 int resident_diag_read(unsigned long long* h24);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,
