@@ -345,7 +345,10 @@ int magma_estep_gather(int M, int nmax, const int64_t* off, const int64_t* off2,
   if ((rc = launch_small_slowpath(M, off, off2, t, y, nullptr, theta, theta_stride, info_out, Kinv, v,
                                   logdet_scratch, nullptr, 0, nullptr, nullptr, st)))
     return rc;
-  if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, 0, st))) return rc;
+  // long lists (many individuals on few grid points, e.g. a common grid: ~M sources per element of
+  // P) take one wavefront per target, short ones (C3: ~6) one thread
+  const double avg_src = ntgt_P > 0 ? 0.5 * (double)M * (double)nmax * (double)nmax / (double)ntgt_P : 0.0;
+  if ((rc = launch_csr_gather_sum(ntgt_P, ptr_P, src_P, tgt_P, Kinv, P, avg_src >= 48.0 ? 1 : 0, st))) return rc;
   return launch_csr_gather_sum(ntgt_w, ptr_w, src_w, tgt_w, v, w, 1, st);
 }
 

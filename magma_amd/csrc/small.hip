@@ -691,19 +691,31 @@ __global__ __launch_bounds__(256) void indiv_gather_cov_kernel(
 // C' = C + (1/M) sum_i r_i r_i' in place of C:
 //   sum_i [r_i' K^-1 r_i + tr(K^-1 C)] = M tr(K^-1 C'),
 //   sum_i [a_i a_i' + K^-1 (C K^-1 - I)] = M [K^-1 C' K^-1 - K^-1],  a_i = K^-1 r_i.
-// dedup_outer_kernel forms S / M (fixed summation order: i ascending), dedup_pack_kernel the
+// dedup_outer_kernel forms S / M (fixed summation order), dedup_pack_kernel the
 // packed C' (layout of indiv_gather_cov_kernel) and the pseudo-individual's outputs y' = mean
 // at its timestamps (so that its residual is exactly 0).
-__global__ __launch_bounds__(64) void dedup_outer_kernel(
+constexpr int DEDUP_PARTS = 16;
+__global__ __launch_bounds__(64 * DEDUP_PARTS) void dedup_outer_kernel(
     int M, int n, const double* __restrict__ y, const int* __restrict__ idx,
     const double* __restrict__ mean, double* __restrict__ S) {
-  const int b = blockIdx.x, a = threadIdx.x;
-  if (a >= n || b >= n) return;
-  const double ma = mean[idx[a]], mb = mean[idx[b]];
+  // workgroup b = column b of S; thread (part, a): individuals part, part + 16, ... in order; the
+  // sixteen partial sums are then added in part order (fixed summation order: repeatable)
+  __shared__ double red[DEDUP_PARTS][64];
+  const int b = blockIdx.x, a = threadIdx.x & 63, part = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int i = 0; i < M; ++i)
-    acc = fma(y[(int64_t)i * n + a] - ma, y[(int64_t)i * n + b] - mb, acc);
-  S[a + (int64_t)n * b] = acc / (double)M;
+  if (a < n && b < n) {
+    const double ma = mean[idx[a]], mb = mean[idx[b]];
+    for (int i = part; i < M; i += DEDUP_PARTS)
+      acc = fma(y[(int64_t)i * n + a] - ma, y[(int64_t)i * n + b] - mb, acc);
+  }
+  red[part][a] = acc;
+  __syncthreads();
+  if (part == 0 && a < n && b < n) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < DEDUP_PARTS; ++q) tot += red[q][a];
+    S[a + (int64_t)n * b] = tot / (double)M;
+  }
 }
 
 __global__ __launch_bounds__(256) void dedup_pack_kernel(
@@ -2415,7 +2427,7 @@ int launch_dedup_prepare(int M, int n, int nmax, const double* y, const int* idx
                          hipStream_t st) {
   if (M < 1 || n < 1 || n > MAGMA_NSMALL_MAX) return fail(2, "dedup: bad sizes");
   const int nc = small_template_nmax(nmax), nt = (nc + 15) / 16;
-  hipLaunchKernelGGL(dedup_outer_kernel, dim3((unsigned)n), dim3(64), 0, st, M, n, y, idx, mean, S);
+  hipLaunchKernelGGL(dedup_outer_kernel, dim3((unsigned)n), dim3(64 * DEDUP_PARTS), 0, st, M, n, y, idx, mean, S);
   hipLaunchKernelGGL(dedup_pack_kernel, dim3(1), dim3(256), 0, st, n, idx, cov, ldc, S, mean, cpack,
                      y_out, nt, nc);
   return check_hip(hipGetLastError(), "dedup_prepare");

@@ -24,6 +24,7 @@ python3 $root/profiles/pmc_summary.py $out/pmc_${cfg}_${steps}_${warm}.json FETC
   SQ_INSTS_VALU_MFMA_MOPS_F64=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 \
   SQ_BUSY_CYCLES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES=$out/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+(cd $root/profiles && python3 mfma_util.py $out $out/mfma_util.json $cfg $steps $warm)
 # compact per-launch timeline (start us, duration us, stream, short kernel name) of the traced run
 python3 - $out <<'PYEOF'
 import csv, glob, sys
