@@ -1631,7 +1631,9 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   const bool with_c = (cpack != nullptr);
   HelpedSums r;
   RSTAMP_INIT();
-  // ---- the board, then K by tile rows (whoever claims them), K^-1 by this wavefront
+  // ---- the board; K and K^-1 by this wavefront (round 3: with the lower-tile build -- 28 exp per
+  // lane -- handing the tile rows of K to the helpers costs more in claims, fences and polls than
+  // the rows themselves: 9.7k cycles on the board against 7.6k alone)
   if (lane == 0) {
     s_parw[0] = p.th1;
     s_parw[1] = p.h;
@@ -1642,25 +1644,9 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   ctl_store(ctl + RO_N, n, lane);
   ctl_store(ctl + RO_EPOCH, epoch, lane);
   ctl_store(ctl + RO_DONE, 0, lane);
-  ctl_store(ctl + RO_BDONE, 0, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  ctl_store(ctl + RO_BLEFT, NT, lane);
-  // (the last tile row, the one with the most tiles, first)
-#pragma unroll
-  for (int it = 0; it < NT; ++it) ctl_store(ctl + RO_BCLAIM + it, 0, lane);
-  for_blocks<NMAX>([&](auto IT) {
-    constexpr int it = NT - 1 - decltype(IT)::value;
-    if (ctl_claim(ctl + RO_BCLAIM + it, lane)) {
-      eval_build_row<NMAX, it>(lane, n, p, tbuf, Ks);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      ctl_add(ctl + RO_BLEFT, -1, lane);
-      ctl_add(ctl + RO_BDONE, 1, lane);
-    }
-  });
-  bool ok = lds_wait_ge(ctl + RO_BDONE, NT, abort_);
-  if (!ok) resident_diag(4, wave, s_ctl);
+  bool ok = true;
   RSTAMP(5);
-  eval_factor<NMAX, true>(lane, n, i, p, tbuf, Ks, nullptr, 0, r.logdet, r.info);
+  eval_factor<NMAX, false>(lane, n, i, p, tbuf, Ks, nullptr, 0, r.logdet, r.info);
   RSTAMP(6);
 
   // ---- the column blocks of stages 4 / 5
@@ -1670,10 +1656,6 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   for (int jt = 0; jt < NT; ++jt) ctl_store(ctl + RO_CLAIM + jt, 0, lane);
   RSTAMP(0);
 
-  __builtin_amdgcn_sched_barrier(0);
-  double cf[NK][NT];
-  if (with_c) eval_load_c<NMAX>(cf, cpack, i, lane);
-  __builtin_amdgcn_sched_barrier(0);
   const double alpha = eval_alpha<NMAX>(lane, Ks, zbuf);
   r.ssq = wave_sum(zr * alpha);
   abuf[lane] = alpha;
@@ -1682,15 +1664,27 @@ __device__ __attribute__((noinline)) HelpedSums resident_helped_eval(
   ctl_store(ctl + RO_AREADY, epoch, lane);
   RSTAMP(1);
 
-  for_blocks<NMAX>([&](auto JT) {
-    constexpr int jt = decltype(JT)::value;
-    if (ctl_claim(ctl + RO_CLAIM + jt, lane)) {
-      resident_do_block<NMAX, jt>(lane, n, p, with_c, cf, Ks, tbuf, abuf, part, [] {});
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      ctl_add(ctl + RO_LEFT, -1, lane);
-      ctl_add(ctl + RO_DONE, 1, lane);
-    }
-  });
+  // the helpers have had the time of alpha to claim the blocks; what is left is this wavefront's
+  // (the packed C is only loaded if there is something left)
+  if (ctl_load(ctl + RO_LEFT) > 0) {
+    bool have_c = false;
+    double cf[NK][NT];
+    for_blocks<NMAX>([&](auto JT) {
+      constexpr int jt = decltype(JT)::value;
+      if (ctl_claim(ctl + RO_CLAIM + jt, lane)) {
+        if (with_c && !have_c) {
+          __builtin_amdgcn_sched_barrier(0);
+          eval_load_c<NMAX>(cf, cpack, i, lane);
+          __builtin_amdgcn_sched_barrier(0);
+          have_c = true;
+        }
+        resident_do_block<NMAX, jt>(lane, n, p, with_c, cf, Ks, tbuf, abuf, part, [] {});
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        ctl_add(ctl + RO_LEFT, -1, lane);
+        ctl_add(ctl + RO_DONE, 1, lane);
+      }
+    });
+  }
   RSTAMP(2);
   if (!lds_wait_ge(ctl + RO_DONE, NT, abort_)) {
     resident_diag(1, wave, s_ctl);
@@ -1879,25 +1873,6 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
       const double* otbuf = oKs + KL<NMAX>::alloc;
       const double* oabuf = otbuf + 128;
       double* opart = oKs + resident_wave_doubles<NMAX>() - 16;
-      if (ctl_load(co + RO_BLEFT) > 0) {  // tile rows of K
-        for_blocks<NMAX>([&](auto IT) {
-          constexpr int it = NT - 1 - decltype(IT)::value;
-          if (ctl_claim(co + RO_BCLAIM + it, lane)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const int on = ctl_load(co + RO_N);
-            SEParams p;
-            p.th1 = s_par[o][0];
-            p.h = s_par[o][1];
-            p.sig2 = s_par[o][2];
-            p.eth1 = s_par[o][3];
-            eval_build_row<NMAX, it>(lane, on, p, otbuf, oKs);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            ctl_add(co + RO_BLEFT, -1, lane);
-            ctl_add(co + RO_BDONE, 1, lane);
-            did = true;
-          }
-        });
-      }
       if (ctl_load(co + RO_LEFT) <= 0) continue;
       for_blocks<NMAX>([&](auto JT) {
         constexpr int jt = decltype(JT)::value;
