@@ -86,7 +86,11 @@ int magma_prof_reset(void);
  * lock step, 0: a task per block step. "dag_max_block_rows" (default 64): the one-launch inverse
  * is used up to this many 64-row blocks. Driver switches (default 1): "prefactor" (the M-step's
  * first K_0 inverse started next to the E-step's), "prefetch" (the next E-step's sums started
- * under the monitoring call), "cov_factor" (theta_0 gradient through the E-step's triangular
+ * under the monitoring call; inside an EM iteration they start right behind the resident M-step
+ * kernel, from the theta_i it leaves in device memory), "speculate" (the next E-step's dense part
+ * queued behind an EM iteration's monitoring evaluation, into a second pair of buffers; taken by
+ * the next E-step only if it is called with exactly those hyper-parameters and prior mean -- the
+ * resident mean / cov of the iteration that queued it are not touched), "cov_factor" (theta_0 gradient through the E-step's triangular
  * factor of cov; one rank, or every rank with "theta0_shard" 0), "theta0_shard" (several ranks: the
  * two N^3 products of the theta_0 gradient split by block rows and two sums all-reduced per
  * evaluation; 0 = every rank forms the whole gradient, nothing exchanged per evaluation). Results

@@ -659,6 +659,10 @@ int magma_set_option(const char* name, long value) {
     set_covfac(value != 0);
     return 0;
   }
+  if (std::string(name) == "speculate") {  // next E-step's dense part queued behind the monitoring call
+    set_speculate(value != 0);
+    return 0;
+  }
   if (std::string(name) == "prefetch") {  // next E-step's sums started under the monitoring call
     set_prefetch(value != 0);
     return 0;

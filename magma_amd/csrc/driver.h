@@ -91,6 +91,8 @@ bool covfac_enabled();
 bool theta0_shard_enabled();
 void set_theta0_shard(bool on);
 void set_covfac(bool on);
+// the next E-step's dense part queued behind an EM iteration's monitoring evaluation (driver.hip)
+void set_speculate(bool on);
 bool prefactor_enabled();
 void set_prefactor(bool on);
 

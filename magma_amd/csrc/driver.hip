@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -73,7 +74,7 @@ int nccl_check(ncclResult_t e, const char* what) {
 // ------------------------------------------------------------------ context
 struct magma_ctx {
   int device = 0, rank = 0, world = 1;
-  hipStream_t main = nullptr, side = nullptr, low = nullptr;
+  hipStream_t main = nullptr, side = nullptr, low = nullptr, sums = nullptr;
   ncclComm_t comm = nullptr;       // RCCL (world > 1), or
   magma_allreduce_fn cb = nullptr;  // a caller-supplied all-reduce
   void* cb_user = nullptr;
@@ -184,7 +185,28 @@ struct magma_dataset {
   hipEvent_t pre_ev = nullptr;
   bool pre_valid = false, pre_issued = false;
   std::vector<double> pre_theta;
+  // ... started even earlier inside an EM iteration: right behind the resident M-step kernel, from
+  // the theta_i it leaves in device memory (want_early: set by magma_em_iteration around its
+  // M-step; pre_early: issued; m_redo: problems were solved again on the host, the device rows are
+  // not the final ones)
+  bool want_early = false, pre_early = false, m_redo = false;
+  hipEvent_t res_ev = nullptr;
+  // The NEXT E-step's dense part, queued behind the monitoring evaluation that ends an EM
+  // iteration (all of its inputs are known then): precision + K_0^-1 -> cov in P2, mean in mean2,
+  // packed cov blocks and factor of cov for the next M-step. Taken by the next magma_e_step when
+  // it is called with exactly these hyper-parameters and prior mean; the current mean / cov
+  // (`param` of a fit that stops here, MG:78) stay where they are.
+  DevBuf mean2;
+  double* h_fin2 = nullptr;
+  hipEvent_t mon_ev = nullptr, spec_ev = nullptr;
+  bool spec_issued = false, spec_cpack = false, spec_fac = false;
+  double spec_key[3] = {0, 0, 0};
+  std::vector<double> spec_m0;
   ~magma_dataset() {
+    if (res_ev) (void)hipEventDestroy(res_ev);
+    if (mon_ev) (void)hipEventDestroy(mon_ev);
+    if (spec_ev) (void)hipEventDestroy(spec_ev);
+    if (h_fin2) (void)hipHostFree(h_fin2);
     if (pre_ev) (void)hipEventDestroy(pre_ev);
     if (pre0_ev) (void)hipEventDestroy(pre0_ev);
     if (h_rres) (void)hipHostFree(h_rres);
@@ -400,6 +422,8 @@ int prefetch_estep_sums(magma_ctx* c, magma_dataset* d, const double* h_theta_i)
   d->pre_valid = false;
   if (d->M == 0 || !prefetch_enabled()) return 0;
   hipStream_t st = c->side;
+  if (d->pre_issued)  // (sums started behind the resident kernel that turned out not to be final)
+    MAGMA_CHECK_HIP(hipStreamWaitEvent(st, d->pre_ev, 0));
   std::vector<double> rows((size_t)(3 * d->M));
   for (int64_t k = 0; k < d->M; ++k)
     for (int q = 0; q < 3; ++q)
@@ -420,6 +444,71 @@ int prefetch_estep_sums(magma_ctx* c, magma_dataset* d, const double* h_theta_i)
   MAGMA_CHECK_HIP(hipEventRecord(d->pre_ev, st));
   d->pre_theta.assign(h_theta_i, h_theta_i + 3 * d->M_total);
   d->pre_valid = true;
+  return 0;
+}
+
+// The same sums started even earlier: on the `sums` stream right behind the resident M-step
+// kernel, from the theta_i rows that kernel leaves in device memory (no host round trip, no
+// second upload). The caller validates them once the M-step's results are on the host.
+int early_estep_sums(magma_ctx* c, magma_dataset* d) {
+  if (d->M == 0 || !prefetch_enabled() || !d->res_ev) return 0;
+  hipStream_t st = c->sums;
+  MAGMA_CHECK_HIP(hipEventRecord(d->res_ev, c->main));
+  MAGMA_CHECK_HIP(hipStreamWaitEvent(st, d->res_ev, 0));
+  if (d->pre_issued) MAGMA_CHECK_HIP(hipStreamWaitEvent(st, d->pre_ev, 0));
+  const size_t Np = (size_t)d->Np;
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->P2.p, 0, sizeof(double) * Np * Np, st));
+  MAGMA_CHECK_HIP(hipMemsetAsync(d->w2.p, 0, sizeof(double) * Np, st));
+  d->pre_issued = true;
+  d->pre_valid = false;
+  if (int rc = magma_estep_gather((int)d->M, d->nmax, d->off.as<int64_t>(), d->off2.as<int64_t>(),
+                                  d->t.as<double>(), d->y.as<double>(), d->rres.as<double>(), 3,
+                                  d->Kinv.as<double>(), d->v.as<double>(), d->f2.as<double>(), d->nP,
+                                  d->ptrP.as<int64_t>(), d->srcP.as<int>(), d->tgtP.as<int64_t>(), d->nw,
+                                  d->ptrw.as<int64_t>(), d->srcw.as<int>(), d->tgtw.as<int64_t>(),
+                                  d->P2.as<double>(), d->w2.as<double>(), d->info2.as<int>(), st))
+    return rc;
+  MAGMA_CHECK_HIP(hipEventRecord(d->pre_ev, st));
+  d->pre_early = true;
+  return 0;
+}
+
+std::atomic<bool> g_speculate{true};
+
+// The next E-step's dense part queued on the main stream behind whatever is there (the monitoring
+// evaluation, whose K_0^-1(theta_0, pen) in d->work it reuses). See magma_dataset::spec_*.
+int speculate_estep(magma_ctx* c, magma_dataset* d, const double* h_theta0, double pen, bool want_cpack) {
+  d->spec_issued = false;
+  if (!g_speculate.load() || c->has_comm() || !d->large.empty() || !d->pre_valid || !d->spec_ev || d->M == 0)
+    return 0;
+  hipStream_t st = c->main;
+  MAGMA_CHECK_HIP(hipStreamWaitEvent(st, d->pre_ev, 0));
+  d->pre_issued = false;  // (consumed: the sums in P2 become the speculative cov in place)
+  d->pre_valid = false;
+  if (int rc = estep_finish_launch(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen,
+                                   d->m0.as<double>(), d->P2.as<double>(), d->w2.as<double>(),
+                                   d->mean2.as<double>(), d->work.p, 1, 1, d->h_fin2, st))
+    return rc;
+  // the packed blocks and the factor now describe the speculative cov, not the current one
+  d->cpack_ok = false;
+  d->covfac_ok = false;
+  d->spec_cpack = want_cpack;
+  if (want_cpack)
+    if (int rc = magma_indiv_gather_cov((int)d->M, d->nmax, d->off.as<int64_t>(), d->idx.as<int>(),
+                                        d->P2.as<double>(), d->N, d->cpack.as<double>(), st))
+      return rc;
+  d->spec_fac = d->covfac.p && covfac_enabled();
+  if (d->spec_fac)
+    if (int rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st)) return rc;
+  if (!d->h_flag)
+    MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_flag, sizeof(int) * (size_t)d->M, hipHostMallocDefault));
+  MAGMA_CHECK_HIP(hipMemcpyAsync(d->h_flag, d->info2.p, sizeof(int) * (size_t)d->M, hipMemcpyDeviceToHost, st));
+  MAGMA_CHECK_HIP(hipEventRecord(d->spec_ev, st));
+  d->spec_key[0] = h_theta0[0];
+  d->spec_key[1] = h_theta0[1];
+  d->spec_key[2] = pen;
+  d->spec_m0 = d->h_m0_last;
+  d->spec_issued = true;
   return 0;
 }
 
@@ -507,6 +596,10 @@ int theta0_f(magma_ctx* c, magma_dataset* d, const double* th0, double pen, doub
 
 }  // namespace
 
+namespace magma {
+void set_speculate(bool on) { g_speculate.store(on); }
+}  // namespace magma
+
 // =================================================================== C ABI
 extern "C" {
 
@@ -530,6 +623,8 @@ static int ctx_common(magma_ctx* c, int device) {
   // not queue behind the wide per-individual launches it overlaps with
   MAGMA_CHECK_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
   MAGMA_CHECK_HIP(hipStreamCreateWithPriority(&c->low, hipStreamNonBlocking, lo));
+  // the next E-step's sums when they are started right behind the resident M-step kernel
+  MAGMA_CHECK_HIP(hipStreamCreateWithFlags(&c->sums, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   MAGMA_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -599,6 +694,7 @@ void magma_ctx_destroy(magma_ctx* c) {
   if (c->main) (void)hipStreamDestroy(c->main);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->low) (void)hipStreamDestroy(c->low);
+  if (c->sums) (void)hipStreamDestroy(c->sums);
   delete c;
 }
 
@@ -759,8 +855,12 @@ int magma_dataset_create(magma_ctx* c, magma_dataset** out, int64_t M, int64_t M
     if ((rc = d->P2.alloc(sizeof(double) * Np * Np)) || (rc = d->w2.alloc(sizeof(double) * Np)) ||
         (rc = d->covfac.alloc(sizeof(double) * Np * Np)) ||
         (rc = d->theta2.alloc(sizeof(double) * 3 * Mb)) || (rc = d->info2.alloc(sizeof(int) * Mb)) ||
-        (rc = d->f2.alloc(sizeof(double) * Mb)))
+        (rc = d->f2.alloc(sizeof(double) * Mb)) || (rc = d->mean2.alloc(sizeof(double) * Np)))
       return rc;
+    MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->res_ev, hipEventDisableTiming));
+    MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->mon_ev, hipEventDisableTiming));
+    MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->spec_ev, hipEventDisableTiming));
+    MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_fin2, 3 * sizeof(double), hipHostMallocDefault));
     MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->pre_ev, hipEventDisableTiming));
     MAGMA_CHECK_HIP(hipEventCreateWithFlags(&d->pre0_ev, hipEventDisableTiming));
   }
@@ -899,6 +999,42 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   HT("e: set_m0");
   if ((rc = set_theta(d, h_theta_i, theta_stride, st))) return rc;
   HT("e: set_theta");
+  if (d->spec_issued) {
+    // the dense part of this very E-step may already be queued (or done): speculate_estep
+    d->spec_issued = false;
+    const bool hit = theta_stride == 3 && d->spec_key[0] == h_theta0[0] && d->spec_key[1] == h_theta0[1] &&
+                     d->spec_key[2] == pen_diag && d->spec_m0 == d->h_m0_last &&
+                     d->pre_theta.size() == (size_t)(3 * d->M_total) &&
+                     std::equal(d->pre_theta.begin(), d->pre_theta.end(), h_theta_i);
+    if (hit) {
+      MAGMA_CHECK_HIP(hipEventSynchronize(d->spec_ev));
+      std::swap(d->P.p, d->P2.p);
+      std::swap(d->w.p, d->w2.p);
+      std::swap(d->info.p, d->info2.p);
+      std::swap(d->mean.p, d->mean2.p);
+      int info = 0;
+      double f0 = 0.0;
+      estep_finish_read(d->h_fin2, &f0, &info);
+      HT("e: finish (sync)");
+      d->a0_valid = (info == 0);
+      d->a0_key[0] = h_theta0[0];
+      d->a0_key[1] = h_theta0[1];
+      d->a0_key[2] = pen_diag;
+      d->last_f0 = f0;
+      d->dedup_ok = false;
+      d->cpack_ok = (info == 0) && d->spec_cpack;
+      d->covfac_ok = (info == 0) && d->spec_fac;
+      d->flag_pending = true;
+      if ((rc = count_flagged(d, st, false))) return rc;
+      if (info == 0 && d->cpack_early && !d->cpack_ok && (rc = ensure_cpack(d, st))) return rc;
+      if (h_info) *h_info = info;
+      if (h_f0) *h_f0 = f0;
+      HT("e: factor + flagged (sync)");
+      return 0;
+    }
+    // not taken: its kernels are ordered on this stream ahead of everything queued below, and the
+    // prefetched sums it consumed are gone (pre_valid is already false)
+  }
   d->cpack_ok = false;
   d->dedup_ok = false;
   const size_t Np = (size_t)d->Np;
@@ -1151,6 +1287,9 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M) + M, st)))
           break;
         start0();
+        d->m_redo = false;
+        d->pre_early = false;
+        if (d->want_early && (rc = early_estep_sums(c, d))) break;
         // x, f, f(x0) and the evaluation counts sit in one block: one copy into pinned memory
         if (!d->h_rres &&
             (rc = check_hip(hipHostMalloc(&d->h_rres, sizeof(double) * 6 * (size_t)M, hipHostMallocDefault),
@@ -1171,6 +1310,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
           for (int64_t i = 0; i < M; ++i)
             if (hn[M + i] == 6) redo.push_back((int)i);
           if (!redo.empty()) {
+            d->m_redo = true;
             const int nr = (int)redo.size();
             std::vector<double> x0((size_t)3 * nr), xr((size_t)3 * nr), fr((size_t)nr), f0r((size_t)nr);
             std::vector<int> nfr((size_t)nr);
@@ -1282,6 +1422,28 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   return 0;
 }
 
+// K_0^-1 of the M-step's first theta_0 evaluation (CF:409: pen_diag = mean(2 sigma_i)) depends on
+// nothing the E-step computes: started on the low-priority stream with a part of the chip, it is
+// ready when the theta_0 chain begins. after_monitoring: queued by the previous EM iteration for
+// the next one; the low stream then waits for that iteration's monitoring evaluation, so that the
+// inverse runs next to the (speculative) E-step's, not next to the monitoring call's.
+static int issue_prefactor(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
+                           bool after_monitoring) {
+  if (!(prefactor_enabled() && d->pre0_ev && d->Np / 64 <= 64 && !d->pre0_issued)) return 0;
+  if (int rc = set_device(c)) return rc;
+  const double pen_m = mean_sigma(d, h_theta_i, 3, 2.0);
+  if (after_monitoring && d->mon_ev) MAGMA_CHECK_HIP(hipStreamWaitEvent(c->low, d->mon_ev, 0));
+  if (int rc = theta0_prefactor_impl(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_m,
+                                     d->work0.p, c->prefactor_wgs, c->low))
+    return rc;
+  MAGMA_CHECK_HIP(hipEventRecord(d->pre0_ev, c->low));
+  d->pre0_issued = true;
+  d->pre0_key[0] = h_theta0[0];
+  d->pre0_key[1] = h_theta0[1];
+  d->pre0_key[2] = pen_m;
+  return 0;
+}
+
 // ------------------------------------------------------------------ one EM iteration (MG:32-75)
 int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, const double* h_theta_i,
                        const double* h_m0, int n_m0, int common_hp, const double* opt4,
@@ -1290,21 +1452,7 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   const double nanv = std::numeric_limits<double>::quiet_NaN();
   const double pen_e = mean_sigma(d, h_theta_i, 3, 1.0);  // CF:381 (signed mean)
   int info = 0;
-  if (prefactor_enabled() && d->pre0_ev && d->Np / 64 <= 64 && !d->pre0_issued) {
-    // K_0^-1 of the M-step's first theta_0 evaluation (CF:409: pen_diag = mean(2 sigma_i)) depends
-    // on nothing the E-step computes: started now on the low-priority stream with a part of the
-    // chip, it is ready when the theta_0 chain begins
-    if (int rc = set_device(c)) return rc;
-    const double pen_m = mean_sigma(d, h_theta_i, 3, 2.0);
-    if (int rc = theta0_prefactor_impl(d->N, d->grid.as<double>(), h_theta0[0], h_theta0[1], pen_m,
-                                       d->work0.p, c->prefactor_wgs, c->low))
-      return rc;
-    MAGMA_CHECK_HIP(hipEventRecord(d->pre0_ev, c->low));
-    d->pre0_issued = true;
-    d->pre0_key[0] = h_theta0[0];
-    d->pre0_key[1] = h_theta0[1];
-    d->pre0_key[2] = pen_m;
-  }
+  if (int rc = issue_prefactor(c, d, h_theta0, h_theta_i, false)) return rc;
   d->cpack_early = !common_hp;
   const int rc_e = magma_e_step(c, d, h_theta0, h_theta_i, 3, pen_e, h_m0, n_m0, &info, nullptr);
   d->cpack_early = false;
@@ -1322,7 +1470,9 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
     return fail(5, std::string("E-step: ") + (info > 0 ? "K_0" : "hyper-posterior precision") +
                        " not positive definite (info=" + std::to_string(info) + ")" + extra);
   }
+  d->want_early = !common_hp;  // the next E-step's sums right behind the resident kernel
   const int rc_m = magma_m_step(c, d, h_theta0, h_theta_i, common_hp, opt4, h_theta0_out, h_theta_i_out);
+  d->want_early = false;
   d->theta_from_estep = false;
   if (rc_m) return rc_m;
   bool bad = std::isnan(h_theta0_out[0]) || std::isnan(h_theta0_out[1]);
@@ -1341,7 +1491,9 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   // E-step's sums (queued on the side stream) runs under it
   const double sig = mean_sigma(d, h_theta_i_out, 3, 1.0);
   if (!d->h_mon) MAGMA_CHECK_HIP(hipHostMalloc((void**)&d->h_mon, 4 * sizeof(double), hipHostMallocDefault));
-  const bool will_prefetch = d->M > 0 && prefetch_enabled();
+  // (a capped grid leaves room for the next E-step's sums when they are launched next to this
+  // inverse; sums that were started behind the resident kernel are mostly over by now)
+  const bool will_prefetch = d->M > 0 && prefetch_enabled() && !(d->pre_early && d->pre_issued && !d->m_redo);
   if (will_prefetch && c->monitor_wgs > 0) set_dag_grid_once(c->monitor_wgs);
   d->stats.theta0_evals += 1;
   d->a0_valid = false;
@@ -1350,10 +1502,29 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
                                       d->work.p, nullptr, nullptr, c->main, nullptr, nullptr, false, d->h_mon);
   set_dag_grid_once(0);
   if (rc_mon) return rc_mon;
+  if (d->mon_ev) MAGMA_CHECK_HIP(hipEventRecord(d->mon_ev, c->main));
   HT("em: monitoring launch");
-  if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) return rc;
+  // the next E-step's sums: already running if they were started behind the resident kernel and
+  // its theta_i rows were the final ones (no problem solved again on the host)
+  const bool early_ok = d->pre_early && d->pre_issued && !d->m_redo;
+  d->pre_early = false;
+  if (early_ok) {
+    d->pre_theta.assign(h_theta_i_out, h_theta_i_out + 3 * d->M_total);
+    d->pre_valid = true;
+  } else if (int rc = prefetch_estep_sums(c, d, h_theta_i_out)) {
+    return rc;
+  }
   HT("em: prefetch launch");
-  if (int rc = sync(c->main)) return rc;
+  // ... and its dense part, behind the monitoring evaluation whose K_0^-1 it shares; then the next
+  // M-step's first K_0^-1 next to it
+  if (int rc = speculate_estep(c, d, h_theta0_out, sig, !common_hp)) return rc;
+  if (d->spec_issued)
+    if (int rc = issue_prefactor(c, d, h_theta0_out, h_theta_i_out, true)) return rc;
+  if (d->mon_ev) {
+    MAGMA_CHECK_HIP(hipEventSynchronize(d->mon_ev));
+  } else if (int rc = sync(c->main)) {
+    return rc;
+  }
   const int info_mon = (int)d->h_mon[3];
   d->a0_valid = (info_mon == 0);
   d->a0_key[0] = h_theta0_out[0];

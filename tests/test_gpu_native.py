@@ -621,3 +621,46 @@ def test_theta0_gradient_through_the_covariance_factor(m):
         _lib.call("magma_set_option", b"cov_factor", 1)
     assert np.abs(out[1][0] - out[0][0]).max() < 1e-8, (out[1][0], out[0][0])
     assert np.array_equal(out[1][1], out[0][1])  # (the theta_i problems do not see the option)
+
+
+def test_speculative_estep_changes_nothing(m):
+    """An EM iteration queues the NEXT E-step's sums right behind its resident M-step kernel and that
+    E-step's dense part behind its monitoring evaluation (driver.hip: early_estep_sums,
+    speculate_estep). With the option off every step is computed when it is asked for: same bits,
+    incl. the hyper-posterior left resident after the last iteration (`param`, MG:78), which the
+    speculation must not touch. A call with other hyper-parameters than the speculated ones
+    ignores it."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    from magma_amd.synth import simu_arrays
+    a = simu_arrays(1500, 30, 300, False, False, seed=21)
+    ds = m.Dataset.from_arrays(a["off"], a["t"], a["y"], grid=a["grid"])
+    out = {}
+    try:
+        for spec in (1, 0):
+            _lib.call("magma_set_option", b"speculate", spec)
+            eng = NativeEngine(ds)
+            th0, thi = np.array([1.0, 1.0]), np.tile([1.0, 1.0, 0.2], (ds.M, 1))
+            tr = []
+            for _ in range(4):
+                th0, thi, lo, ln = eng.em_iteration(th0, thi, 0.3, False)
+                tr.append((lo, ln))
+            res = [th0.copy(), thi.copy(), np.array(tr), eng.get_mean(), eng.get_cov()]
+            # a miss: other theta_0 than the one the last iteration speculated on
+            other0 = th0 + np.array([0.05, -0.02])
+            assert eng.e_step(other0, thi, float(np.mean(thi[:, 2])), 0.3) == 0
+            res += [eng.get_mean(), eng.get_cov(), eng.last_f0]
+            # and an iteration from there (the speculation of the iteration before is stale)
+            n0, ni, lo, ln = eng.em_iteration(other0, thi, 0.3, False)
+            res += [n0, ni, np.array([lo, ln])]
+            out[spec] = res
+            eng.close()
+    finally:
+        _lib.call("magma_set_option", b"speculate", 1)
+    for x, y in zip(out[1], out[0]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    fresh = NativeEngine(ds)
+    th0, thi = out[1][0] + np.array([0.05, -0.02]), out[1][1]
+    assert fresh.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.3) == 0
+    assert np.array_equal(fresh.get_cov(), out[1][6]) and fresh.last_f0 == out[1][7]
+    fresh.close()
