@@ -90,7 +90,8 @@ int magma_prof_reset(void);
  * kernel, from the theta_i it leaves in device memory), "speculate" (the next E-step's dense part
  * queued behind an EM iteration's monitoring evaluation, into a second pair of buffers; taken by
  * the next E-step only if it is called with exactly those hyper-parameters and prior mean -- the
- * resident mean / cov of the iteration that queued it are not touched), "cov_factor" (theta_0 gradient through the E-step's triangular
+ * resident mean / cov of the iteration that queued it are not touched), "resident_gather" (the resident M-step kernel gathers each individual's packed cov block
+ * itself instead of a magma_indiv_gather_cov launch between E-step and M-step), "cov_factor" (theta_0 gradient through the E-step's triangular
  * factor of cov; one rank, or every rank with "theta0_shard" 0), "theta0_shard" (several ranks: the
  * two N^3 products of the theta_0 gradient split by block rows and two sums all-reduced per
  * evaluation; 0 = every rank forms the whole gradient, nothing exchanged per evaluation). Results

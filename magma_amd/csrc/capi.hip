@@ -679,6 +679,10 @@ int magma_set_option(const char* name, long value) {
     set_resident_help((int)value);
     return 0;
   }
+  if (std::string(name) == "resident_gather") {  // driver: packed cov blocks gathered inside the resident kernel
+    set_resident_gather(value != 0);
+    return 0;
+  }
   if (std::string(name) == "resident_slow_path") {  // status 6 on every flagged point, not only the start
     set_resident_slow_path((int)value);
     return 0;

@@ -1026,7 +1026,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
       d->covfac_ok = (info == 0) && d->spec_fac;
       d->flag_pending = true;
       if ((rc = count_flagged(d, st, false))) return rc;
-      if (info == 0 && d->cpack_early && !d->cpack_ok && (rc = ensure_cpack(d, st))) return rc;
+      if (info == 0 && d->cpack_early && !d->cpack_ok && !resident_gather_enabled() && (rc = ensure_cpack(d, st))) return rc;
       if (h_info) *h_info = info;
       if (h_f0) *h_f0 = f0;
       HT("e: factor + flagged (sync)");
@@ -1110,7 +1110,7 @@ int magma_e_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
   // hyper-parameters the M-step's first need is the packed cov blocks; and the factor of cov for
   // the theta_0 gradient.
   const bool want_fac = (!c->has_comm() || !theta0_shard_enabled()) && d->covfac.p && covfac_enabled();
-  if (d->cpack_early && (rc = ensure_cpack(d, st))) return rc;
+  if (d->cpack_early && !resident_gather_enabled() && (rc = ensure_cpack(d, st))) return rc;
   if (want_fac && (rc = estep_cov_factor(d->N, d->work.p, d->covfac.as<double>(), st))) return rc;
   if (d->M > 0) {  // individuals whose K_i was not positive definite (they took the solve() / ginv() slow path)
     if (!d->h_flag)
@@ -1269,8 +1269,12 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
     if (M > 0) {
       do {
         HT("m: sync + thread start");
-        if ((rc = ensure_cpack(d, st))) break;
+        // the packed cov blocks: gathered by the resident kernel itself, each block by the
+        // wavefront that starts that individual (no launch between the E-step and this kernel)
+        const bool in_kernel_gather = !d->cpack_ok && resident_gather_enabled();
+        if (!in_kernel_gather && (rc = ensure_cpack(d, st))) break;
         if (!d->theta_from_estep && (rc = set_theta(d, h_theta_i, 3, st))) break;
+        if (in_kernel_gather) set_resident_gather_thread(d->P.as<double>(), d->Np);
         HT("m: cpack + theta");
         const int* order = nullptr;
         // longest chains of the previous call first (they tend to stay the longest); the
@@ -1286,6 +1290,7 @@ int magma_m_step(magma_ctx* c, magma_dataset* d, const double* h_theta0, const d
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M),
                                              reinterpret_cast<int*>(d->rres.as<double>() + 5 * M) + M, st)))
           break;
+        if (in_kernel_gather) d->cpack_ok = true;  // (valid once this stream has passed the kernel)
         start0();
         d->m_redo = false;
         d->pre_early = false;
@@ -1517,7 +1522,7 @@ int magma_em_iteration(magma_ctx* c, magma_dataset* d, const double* h_theta0, c
   HT("em: prefetch launch");
   // ... and its dense part, behind the monitoring evaluation whose K_0^-1 it shares; then the next
   // M-step's first K_0^-1 next to it
-  if (int rc = speculate_estep(c, d, h_theta0_out, sig, !common_hp)) return rc;
+  if (int rc = speculate_estep(c, d, h_theta0_out, sig, !common_hp && !resident_gather_enabled())) return rc;
   if (d->spec_issued)
     if (int rc = issue_prefactor(c, d, h_theta0_out, h_theta_i_out, true)) return rc;
   if (d->mon_ev) {

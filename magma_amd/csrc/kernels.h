@@ -28,6 +28,9 @@ void set_resident_max_workgroups(int v);         // process default (option "res
 void set_resident_max_workgroups_thread(int v);  // the calling thread's launches; -1 = the default
 void set_resident_help(int v);
 void set_panel_blocks(int v);
+void set_resident_gather_thread(const double* cov, int64_t ld);
+bool resident_gather_enabled();
+void set_resident_gather(bool on);
 void set_resident_slow_path(int v);
 int resident_diag_read(unsigned long long* h24);
 int launch_indiv_gather_cov(int M, int nmax, const int64_t* off, const int* idx,

@@ -1712,12 +1712,12 @@ template <int NMAX>
 __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>() / 4) void indiv_mstep_kernel(
     int M, const int* __restrict__ order, const int64_t* __restrict__ off,
     const double* __restrict__ t, const double* __restrict__ y, const int* __restrict__ idx,
-    const double* __restrict__ mean, const double* __restrict__ cpack, int mode,
+    const double* __restrict__ mean, const double* cpack, int mode,
     const double* __restrict__ theta0, int lm,
     double factr, double pgtol, int maxit, double* __restrict__ theta_out,
     double* __restrict__ f_out, double* __restrict__ fx0_out, int* __restrict__ iters_out,
     int* __restrict__ nfev_out, int* __restrict__ status_out, int* __restrict__ ticket,
-    int help_on, int slow_all) {
+    int help_on, int slow_all, const double* __restrict__ gather_cov, int64_t gather_ld) {
   constexpr int NT = (NMAX + 15) / 16, NK = NMAX / 4;
   constexpr int RW = resident_waves<NMAX>();
   static_assert(NT <= 4, "four claim words per board");
@@ -1760,6 +1760,27 @@ __global__ __launch_bounds__(64 * resident_waves<NMAX>(), resident_waves<NMAX>()
       zbuf[lane0] = rv ? (y[o + lane0] - mean[idx[o + lane0]]) : 0.0;
       lbcore::init(*st, 3, lm, theta0 + 3 * (int64_t)i);
       wave_sync();
+      if (gather_cov != nullptr && cpack != nullptr) {
+        // This individual's block C_i = cov[idx_i, idx_i] into its slot of the packed array
+        // (layout of indiv_gather_cov_kernel), by the wavefront that is about to use it: the
+        // separate gather launch (0.2 ms between the E-step and this kernel) is gone, its reads
+        // are spread under the other wavefronts' evaluations. cov is symmetric in memory.
+        int* ib = reinterpret_cast<int*>(abuf);
+        ib[lane0] = rv ? idx[o + lane0] : 0;
+        wave_sync();
+        constexpr int TOT = 16 * NT * NMAX;
+        double* out = const_cast<double*>(cpack) + (int64_t)i * TOT;
+#pragma unroll 13
+        for (int e = lane0; e < TOT; e += 64) {
+          const int it = e % NT, ln = (e / NT) & 63, kk = e / (64 * NT);
+          const int r = 16 * it + (ln & 15), c = 4 * kk + (ln >> 4);
+          const bool in = r < n && c < n;
+          const double v = gather_cov[(int64_t)ib[in ? c : 0] * gather_ld + ib[in ? r : 0]];
+          out[e] = in ? v : 0.0;
+        }
+        __threadfence();  // the block is read back through other instructions (and by helpers)
+        wave_sync();
+      }
       fresh = false;
     }
     // lane is laundered per evaluation: otherwise every lane-derived address and mask of the
@@ -2279,6 +2300,17 @@ static std::atomic<int> g_resident_max_wgs{0};
 static thread_local int t_resident_max_wgs = -1;
 void set_resident_max_workgroups(int v) { g_resident_max_wgs.store(v < 0 ? 0 : v); }
 void set_resident_max_workgroups_thread(int v) { t_resident_max_wgs = v; }
+// The next resident launch of this host thread gathers every individual's packed cov block from
+// `cov` itself (instead of expecting magma_indiv_gather_cov to have run): the driver's route.
+static thread_local const double* t_resident_gather_cov = nullptr;
+static thread_local int64_t t_resident_gather_ld = 0;
+void set_resident_gather_thread(const double* cov, int64_t ld) {
+  t_resident_gather_cov = cov;
+  t_resident_gather_ld = ld;
+}
+static std::atomic<bool> g_resident_gather{true};
+bool resident_gather_enabled() { return g_resident_gather.load(); }
+void set_resident_gather(bool on) { g_resident_gather.store(on); }
 // Idle wavefronts help the running ones of their workgroup (default on; same results either way).
 static std::atomic<int> g_resident_help{1};
 void set_resident_help(int v) { g_resident_help.store(v & 3); }
@@ -2358,10 +2390,13 @@ static int launch_indiv_mstep_t(int M, const int* order, const int64_t* off, con
   int grid = (M + RW - 1) / RW;
   if (grid > cus || (g_resident_help.load(std::memory_order_relaxed) & 2)) grid = cus;  // persistent: one workgroup fills a compute unit
   if (cap > 0 && grid > cap) grid = cap;
+  const double* gsrc = t_resident_gather_cov;
+  const int64_t gld = t_resident_gather_ld;
+  t_resident_gather_cov = nullptr;  // (one launch only)
   hipLaunchKernelGGL(indiv_mstep_kernel<NM>, dim3(grid), dim3(64 * RW), dyn, st, M, order, off,
                      t, y, idx, mean, cpack, mode, theta0, lm, factr, pgtol, maxit, theta_out, f_out,
                      fx0_out, iters, nfev, status, ticket, g_resident_help.load(std::memory_order_relaxed) & 1,
-                     g_resident_slow.load(std::memory_order_relaxed));
+                     g_resident_slow.load(std::memory_order_relaxed), gsrc, gld);
   return check_hip(hipGetLastError(), "indiv_mstep");
 }
 

@@ -664,3 +664,33 @@ def test_speculative_estep_changes_nothing(m):
     assert fresh.e_step(th0, thi, float(np.mean(thi[:, 2])), 0.3) == 0
     assert np.array_equal(fresh.get_cov(), out[1][6]) and fresh.last_f0 == out[1][7]
     fresh.close()
+
+
+@pytest.mark.parametrize("sizes", [[30] * 40, [30, 12, 40, 7, 25, 33, 1, 64, 50, 50, 52, 49]], ids=["uniform", "ragged"])
+def test_packed_cov_blocks_gathered_inside_the_resident_kernel(m, sizes):
+    """`new_cov[paste0('X', t_i), paste0('X', t_i)]` (CF:188, 312): the driver lets the resident
+    M-step kernel gather each individual's block itself (option "resident_gather", default) instead
+    of launching magma_indiv_gather_cov between the E-step and the M-step: same bits."""
+    from magma_amd import _lib
+    from magma_amd.native import NativeEngine
+    rng = np.random.default_rng(len(sizes))
+    db = _ragged_db(rng, sizes)
+    ds = m.Dataset(db)
+    out = {}
+    try:
+        for g in (1, 0):
+            _lib.call("magma_set_option", b"resident_gather", g)
+            eng = NativeEngine(ds)
+            th0 = np.array([0.9, 0.7])
+            thi = np.tile([1.0, 1.0, 0.2], (ds.M, 1)) + np.random.default_rng(3).uniform(-0.3, 0.3, size=(ds.M, 3))
+            res = []
+            for _ in range(3):
+                th0, thi, lo, ln = eng.em_iteration(th0, thi, 0.4, False)
+                res += [th0.copy(), thi.copy(), np.array([lo, ln])]
+            res.append(eng.logL_monitoring(th0, thi))  # (reads the packed blocks after the M-step)
+            out[g] = res
+            eng.close()
+    finally:
+        _lib.call("magma_set_option", b"resident_gather", 1)
+    for x, y in zip(out[1], out[0]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
