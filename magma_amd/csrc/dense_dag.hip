@@ -53,6 +53,7 @@ struct DagArgs {
   int* ctrl;   // [0] ticket counter, [1] abort word, [2], [3] diagnostics, [4] walker claim
   int* fH;     // nt flags (walker mode): S~_jj and B_j of block step j parked in L(j,j) / L(j,j-1)
   int* fS;     // nt flags (walker 2): S~_jj parked by its own task HS(j); fH[j] then announces B_j only
+  int* fV;     // nt flags (walker 2): V_{j,j-2} = A_{j,j-2} - sum_{k<j-2} L_jk L_{j-2,k}^T parked in tile (j, j-2) of U
   int walker;  // 1, 2: one workgroup (the first to start) walks the chain of diagonal tiles (dag_walker / dag_walker2)
   double* logdet;
   int* info;
@@ -136,16 +137,17 @@ __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* 
   int ready = poll_ready(fA, fB, k0, k1, ctrl, s_ready);
   if (ready < 0) return false;
   v4u ta[4][2], tb[4][2];
+  auto fetch_slab = [&](int k, int s) {
+    const unsigned col = (unsigned)(64 * k + 16 * s + kr) * (unsigned)ld;
+    const unsigned oa = (offA + x4 + col) * 8u, ob = (offB + x4 + col) * 8u;
+    ta[s][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa, 0, AUX_SC1);
+    ta[s][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa + 16u, 0, AUX_SC1);
+    tb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob, 0, AUX_SC1);
+    tb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob + 16u, 0, AUX_SC1);
+  };
   auto fetch = [&](int k) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const unsigned col = (unsigned)(64 * k + 16 * s + kr) * (unsigned)ld;
-      const unsigned oa = (offA + x4 + col) * 8u, ob = (offB + x4 + col) * 8u;
-      ta[s][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa, 0, AUX_SC1);
-      ta[s][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, oa + 16u, 0, AUX_SC1);
-      tb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob, 0, AUX_SC1);
-      tb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rb, ob + 16u, 0, AUX_SC1);
-    }
+    for (int s = 0; s < 4; ++s) fetch_slab(k, s);
   };
   fetch(k0);
   // two slab buffers (the second pair in S2, LDS the tile tasks do not otherwise use): slab s + 1
@@ -172,28 +174,52 @@ __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* 
         *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4]) = tb[s + 1][0];
         *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4 + 2]) = tb[s + 1][1];
       }
-      if (s == 3 && pf) fetch(k + 1);
-      const double* Ac = Ab[s & 1];
-      const double* Bc = Bb[s & 1];
-#pragma unroll
-      for (int kk = 0; kk < 16; kk += 4) {
-        const double fa0 = Ac[kk * TLD + fo + wm * 32];
-        const double fa1 = Ac[kk * TLD + fo + wm * 32 + 16];
-        const double fb0 = Bc[kk * TLD + fo + wn * 32];
-        const double fb1 = Bc[kk * TLD + fo + wn * 32 + 16];
-        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc.c[0][0], 0, 0, 0);
-        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc.c[0][1], 0, 0, 0);
-        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc.c[1][0], 0, 0, 0);
-        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc.c[1][1], 0, 0, 0);
-        if constexpr (SELF) {
-          const double fs0 = Ac[kk * TLD + fo + wn * 32];
-          const double fs1 = Ac[kk * TLD + fo + wn * 32 + 16];
-          accS.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa0, accS.c[0][0], 0, 0, 0);
-          accS.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs0, fa1, accS.c[0][1], 0, 0, 0);
-          accS.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa0, accS.c[1][0], 0, 0, 0);
-          accS.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs1, fa1, accS.c[1][1], 0, 0, 0);
+      // the next tile's loads go out as this tile's registers come free (slabs 0 and 1 have been
+      // staged once slab 1 is in LDS, slab 2 and 3 one step later each): its first slab has been
+      // in flight for three slabs of MFMAs when the loop comes round, not for one
+      if (pf) {
+        if (s == 0) {
+          fetch_slab(k + 1, 0);
+          fetch_slab(k + 1, 1);
+        } else if (s == 1) {
+          fetch_slab(k + 1, 2);
+        } else if (s == 2) {
+          fetch_slab(k + 1, 3);
         }
       }
+      const double* Ac = Ab[s & 1];
+      const double* Bc = Bb[s & 1];
+      // the slab's fragment reads all go out before its first MFMA (left alone the compiler puts
+      // each k-group's reads right in front of its MFMAs and waits: four exposed LDS latencies per
+      // slab with one wavefront per SIMD)
+      double fa[4][2], fb[4][2], fs[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 4 * q;
+        fa[q][0] = Ac[kk * TLD + fo + wm * 32];
+        fa[q][1] = Ac[kk * TLD + fo + wm * 32 + 16];
+        fb[q][0] = Bc[kk * TLD + fo + wn * 32];
+        fb[q][1] = Bc[kk * TLD + fo + wn * 32 + 16];
+        if constexpr (SELF) {
+          fs[q][0] = Ac[kk * TLD + fo + wn * 32];
+          fs[q][1] = Ac[kk * TLD + fo + wn * 32 + 16];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][0], fa[q][0], acc.c[0][0], 0, 0, 0);
+        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][0], fa[q][1], acc.c[0][1], 0, 0, 0);
+        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][1], fa[q][0], acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][1], fa[q][1], acc.c[1][1], 0, 0, 0);
+        if constexpr (SELF) {
+          accS.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][0], fa[q][0], accS.c[0][0], 0, 0, 0);
+          accS.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][0], fa[q][1], accS.c[0][1], 0, 0, 0);
+          accS.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][1], fa[q][0], accS.c[1][0], 0, 0, 0);
+          accS.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][1], fa[q][1], accS.c[1][1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < 4) __syncthreads();
     }
     if (more && !pf) {
@@ -797,6 +823,41 @@ __device__ __forceinline__ void dag_walker2(const DagArgs& a, rsrc_t rL, rsrc_t 
 
 constexpr int DAG_LDS_V = 64 * TLD;  // staged tile (V / result / the diagonal block's S and X)
 
+// L_{i,i-2} = V X_{i-2,i-2}^T formed by the calling task for its own use (i >= 2; the product of
+// F(i,i-2), bit for bit), left in LDS as Vs[k * TLD + m] = L(m, k). V = A_{i,i-2} - sum_{k<i-2} L_ik
+// L_{i-2,k}^T is complete a block step before X_{i-2,i-2} exists: F(i,i-2) parks it in the (unused)
+// lower tile (i, i-2) of U behind fV[i] on its way, and the tasks HB(i) and HS(i) fetch it ahead
+// of time. The caller passes a barrier (or a poll_ready) before it reads Vs.
+__device__ __forceinline__ bool own_tile_left2(const DagArgs& a, rsrc_t rL, rsrc_t rU, int i, double* Vs,
+                                               double* Bs, double* Ss, int* s_ready) {
+  const int nt = a.nt, ld = a.ld, c = i - 2;
+  if (poll_ready(a.fV + i, a.fV + i, 0, 1, a.ctrl, s_ready) < 0) return false;
+  {
+    const int tid = threadIdx.x;
+    const int m2 = (tid & 31) * 2;
+    const unsigned off = (unsigned)i * NB + (unsigned)c * NB * (unsigned)ld;
+    v4u v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int n = q * 8 + (tid >> 5);
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(rU, (off + m2 + (unsigned)n * (unsigned)ld) * 8u, 0, AUX_SC1);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int n = q * 8 + (tid >> 5);
+      *reinterpret_cast<v4u*>(&Vs[n * TLD + m2]) = v[q];
+    }
+  }
+  TileAcc out;
+  tile_zero(out);
+  if (!times_xt(Vs, rL, (unsigned)c * NB * (unsigned)(ld + 1), a.fL + c * nt + c, ld, out, Bs, Ss, a.ctrl,
+                s_ready, nullptr))
+    return false;
+  __syncthreads();  // every wavefront has read Vs
+  tile_foreach(out, [&](int m, int n, double v) { Vs[n * TLD + m] = v; });
+  return true;
+}
+
 __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
   __shared__ __attribute__((aligned(16))) double Vs[DAG_LDS_V];
   __shared__ __attribute__((aligned(16))) double Ws[DAG_LDS_V];
@@ -870,10 +931,22 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       // ---- HB(j) (walker 2): B_j = A_{j,j-1} - sum_{k<j-1} L_jk L_{j-1,k}^T alone. Its last term
       // needs the walker's own L_{j-1,j-2}, so it sits on the walker's critical cycle: S~_jj, which
       // does not, has a task of its own (HS below) and half the MFMAs are gone from this one.
+      // That last term's other factor, L_{j,j-2}, used to arrive through memory from F(j,j-2): X
+      // seen -> product -> store -> flag -> poll here -> load -> product, 8-9 us after X_{j-2,j-2}
+      // with the walker's updaters waiting for B_j half of every step. Now this task forms
+      // L_{j,j-2} itself (the same sums and the same product as F(j,j-2), which still publishes the
+      // tile for everybody else) and takes the term from LDS: one hand-off less on the cycle.
       tile_load_neg(acc, a.A + (int64_t)j * NB + (int64_t)(j - 1) * NB * ld, ld);
-      if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB, a.fL + (j - 1) * nt,
-                    0, j - 1, ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
-        return abandon(a.info);
+      if (j >= 2) {
+        if (!acc_rows(rL, (unsigned)j * NB, a.fL + j * nt, rL, (unsigned)(j - 1) * NB, a.fL + (j - 1) * nt,
+                      0, j - 2, ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
+          return abandon(a.info);
+        if (!own_tile_left2(a, rL, rU, j, Vs, Bs, Ss, &s_ready)) return abandon(a.info);
+        // acc += L_{j,j-2} (LDS) L_{j-1,j-2}^T (the walker's, behind its flag)
+        if (!times_xt(Vs, rL, (unsigned)(j - 1) * NB + (unsigned)(j - 2) * NB * (unsigned)ld,
+                      a.fL + (j - 1) * nt + (j - 2), ld, acc, Bs, Ss, a.ctrl, &s_ready, nullptr))
+          return abandon(a.info);
+      }
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Ws[n * TLD + m] = -v; });
       __syncthreads();
@@ -884,12 +957,18 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
     }
     if (r == 1 && a.walker == 2 && j + 1 < nt) {
       // ---- HS(j+1) (walker 2, in the slot of F(j+1,j), which the walker computes):
-      // S~_{j+1,j+1} = A_{j+1,j+1} - sum_{k<j} L_{j+1,k} L_{j+1,k}^T, parked in tile (j+1, j+1)
+      // S~_{j+1,j+1} = A_{j+1,j+1} - sum_{k<j} L_{j+1,k} L_{j+1,k}^T, parked in tile (j+1, j+1). Its
+      // last term, k = j-1, from this task's own copy of L_{j+1,j-1} in LDS (see HB above).
       const int i = j + 1;
       tile_load_neg(acc, a.A + (int64_t)i * NB * (ld + 1), ld);
-      if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)i * NB, a.fL + i * nt, 0, j, ld,
-                    acc, As, Bs, Ss, a.ctrl, &s_ready))
-        return abandon(a.info);
+      if (i >= 2) {
+        if (!acc_rows(rL, (unsigned)i * NB, a.fL + i * nt, rL, (unsigned)i * NB, a.fL + i * nt, 0, i - 2,
+                      ld, acc, As, Bs, Ss, a.ctrl, &s_ready))
+          return abandon(a.info);
+        if (!own_tile_left2(a, rL, rU, i, Vs, Bs, Ss, &s_ready)) return abandon(a.info);
+        __syncthreads();  // L_{i,i-2} staged by every wavefront
+        lds_product64(Vs, Vs, acc);
+      }
       __syncthreads();
       tile_foreach(acc, [&](int m, int n, double v) { Vs[n * TLD + m] = -v; });
       __syncthreads();
@@ -1043,6 +1122,12 @@ __global__ __launch_bounds__(256) void spd_inverse_dag_kernel(DagArgs a) {
       offOut = (unsigned)i * NB + (unsigned)j * NB * (unsigned)ld;
       rOut = rL;
       flag = a.fL + i * nt + j;
+      if (a.walker == 2 && r == 2) {
+        // V_{i,i-2}, complete a block step before X_jj: parked for HB(i) and HS(i) (own_tile_left2)
+        __syncthreads();
+        store_tile_sc1(Vs, rU, offOut, ld);
+        publish(a.fV + i, nullptr);
+      }
     } else {
       // ---- T(c,j), c < j
       const int c = r - (nt - j);
@@ -1084,7 +1169,7 @@ __global__ __launch_bounds__(256) void dag_init_kernel(int* __restrict__ ctrl, i
 }
 
 size_t spd_inverse_dag_ctrl_bytes(int nt) {
-  return (((size_t)(8 + 2 * nt * nt + 2 * nt) * sizeof(int)) + 255) & ~(size_t)255;
+  return (((size_t)(8 + 2 * nt * nt + 3 * nt) * sizeof(int)) + 255) & ~(size_t)255;
 }
 
 static int g_dag_workgroups = 256;
@@ -1123,6 +1208,7 @@ int launch_spd_inverse_dag(int Np, double* A, double* logdet, int* info, double*
   a.fU = ctrl + 8 + nt * nt;
   a.fH = ctrl + 8 + 2 * nt * nt;
   a.fS = a.fH + nt;
+  a.fV = a.fS + nt;
   a.walker = g_dag_walker < 0 ? 0 : (g_dag_walker > 2 ? 2 : g_dag_walker);
   a.logdet = logdet;
   a.info = info;
