@@ -28,6 +28,7 @@
 // the stream reads them).
 // Every spin is bounded: a workgroup that waits ~seconds raises the abort word, every workgroup
 // leaves at its next poll or ticket, and info is set to -999.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "mfma_sweep.h"
@@ -150,84 +151,144 @@ __device__ __forceinline__ bool acc_rows_t(rsrc_t ra, unsigned offA, const int* 
     for (int s = 0; s < 4; ++s) fetch_slab(k, s);
   };
   fetch(k0);
-  // two slab buffers (the second pair in S2, LDS the tile tasks do not otherwise use): slab s + 1
-  // is written while slab s is multiplied, one barrier per slab instead of two
+  // Two slab buffers (the second pair in S2, LDS the tile tasks do not otherwise use). The slabs
+  // form one pipeline that runs on across tiles while the next tile is known to be published, and
+  // everything that is not an MFMA is placed BETWEEN the 16 MFMAs of a slab (one wavefront per
+  // SIMD issues in order: what follows a run of MFMAs in program order waits for all of them to
+  // issue, 64 cycles each, and measured that way a tile product was 1.9 us of staging, barriers
+  // and fragment reads PLUS 1.4 us of MFMAs): slab g + 1 goes to LDS under the first four MFMAs
+  // of slab g, fragment groups 2 and 3 of slab g are read under the next two, the next tile's
+  // loads go out under the two after, the barrier that makes slab g + 1 visible sits in front of
+  // the last group, and groups 0 and 1 of slab g + 1 are read under that group. Same MFMAs on
+  // the same operands in the same order: results are bit-identical.
   double* Ab[2] = {As, S2};
   double* Bb[2] = {Bs, S2 + 16 * TLD};
-#pragma unroll 1
-  for (int k = k0; k < k1; ++k) {
-    const bool more = k + 1 < k1;
-    const bool pf = more && (k + 1) < ready;
-    __syncthreads();  // both buffers free (the previous tile's last slabs have been read)
-    *reinterpret_cast<v4u*>(&Ab[0][kr * TLD + x4]) = ta[0][0];
-    *reinterpret_cast<v4u*>(&Ab[0][kr * TLD + x4 + 2]) = ta[0][1];
-    *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4]) = tb[0][0];
-    *reinterpret_cast<v4u*>(&Bb[0][kr * TLD + x4 + 2]) = tb[0][1];
-    __syncthreads();
+  double fa[2][4][2], fb[2][4][2], fs[2][4][2];
+  auto stage_part = [&](int s, int part) {  // registers of slab s -> buffer s & 1, in four parts
+    double* An = Ab[s & 1];
+    double* Bn = Bb[s & 1];
+    if (part == 0) *reinterpret_cast<v4u*>(&An[kr * TLD + x4]) = ta[s][0];
+    if (part == 1) *reinterpret_cast<v4u*>(&An[kr * TLD + x4 + 2]) = ta[s][1];
+    if (part == 2) *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4]) = tb[s][0];
+    if (part == 3) *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4 + 2]) = tb[s][1];
+  };
+  auto read_group = [&](int p, int q) {  // k-group q of the slab in buffer p -> fragment set p
+    const double* Ac = Ab[p];
+    const double* Bc = Bb[p];
+    const int kk = 4 * q;
+    fa[p][q][0] = Ac[kk * TLD + fo + wm * 32];
+    fa[p][q][1] = Ac[kk * TLD + fo + wm * 32 + 16];
+    fb[p][q][0] = Bc[kk * TLD + fo + wn * 32];
+    fb[p][q][1] = Bc[kk * TLD + fo + wn * 32 + 16];
+    if constexpr (SELF) {
+      fs[p][q][0] = Ac[kk * TLD + fo + wn * 32];
+      fs[p][q][1] = Ac[kk * TLD + fo + wn * 32 + 16];
+    }
+  };
+  // MFMA e (0..3) of k-group q; with SELF the two accumulators' MFMAs alternate
+  auto mfma1 = [&](int p, int q, int e) {
+    const int ni = e >> 1, mi = e & 1;
+    acc.c[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[p][q][ni], fa[p][q][mi], acc.c[ni][mi], 0, 0, 0);
+  };
+  auto mfmaS = [&](int p, int q, int e) {
+    if constexpr (SELF) {
+      const int ni = e >> 1, mi = e & 1;
+      accS.c[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[p][q][ni], fa[p][q][mi], accS.c[ni][mi], 0, 0, 0);
+    }
+  };
+#define MAGMA_SB() __builtin_amdgcn_sched_barrier(0)
+  // One tile. PF: tile k + 1 is known to be published -- its loads go out as this tile's registers
+  // come free and its first slab is staged under this tile's last one, so that the pipeline runs
+  // on (a separate, branch-free instantiation: with the loads behind run-time conditions the
+  // compiler's wait-count pass falls back to vmcnt(0) in front of the staging stores, i.e. waits
+  // for the loads it issued one slab ago).
+  auto tile = [&](auto pf_tag, int k) {
+    constexpr bool PF = decltype(pf_tag)::value;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
-        double* An = Ab[(s + 1) & 1];
-        double* Bn = Bb[(s + 1) & 1];
-        *reinterpret_cast<v4u*>(&An[kr * TLD + x4]) = ta[s + 1][0];
-        *reinterpret_cast<v4u*>(&An[kr * TLD + x4 + 2]) = ta[s + 1][1];
-        *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4]) = tb[s + 1][0];
-        *reinterpret_cast<v4u*>(&Bn[kr * TLD + x4 + 2]) = tb[s + 1][1];
-      }
-      // the next tile's loads go out as this tile's registers come free (slabs 0 and 1 have been
-      // staged once slab 1 is in LDS, slab 2 and 3 one step later each): its first slab has been
-      // in flight for three slabs of MFMAs when the loop comes round, not for one
-      if (pf) {
-        if (s == 0) {
-          fetch_slab(k + 1, 0);
-          fetch_slab(k + 1, 1);
-        } else if (s == 1) {
-          fetch_slab(k + 1, 2);
-        } else if (s == 2) {
-          fetch_slab(k + 1, 3);
-        }
-      }
-      const double* Ac = Ab[s & 1];
-      const double* Bc = Bb[s & 1];
-      // the slab's fragment reads all go out before its first MFMA (left alone the compiler puts
-      // each k-group's reads right in front of its MFMAs and waits: four exposed LDS latencies per
-      // slab with one wavefront per SIMD)
-      double fa[4][2], fb[4][2], fs[4][2];
+      const int p = s & 1;
+      const bool follows = (s < 3) || PF;  // another slab of the pipeline follows this one
+      const int sn = (s + 1) & 3;          // its index in ta / tb (slab 0 of tile k + 1 after slab 3)
+      MAGMA_SB();
+      // group 0: the next slab goes to LDS (its buffer was last read before the previous barrier)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = 4 * q;
-        fa[q][0] = Ac[kk * TLD + fo + wm * 32];
-        fa[q][1] = Ac[kk * TLD + fo + wm * 32 + 16];
-        fb[q][0] = Bc[kk * TLD + fo + wn * 32];
-        fb[q][1] = Bc[kk * TLD + fo + wn * 32 + 16];
-        if constexpr (SELF) {
-          fs[q][0] = Ac[kk * TLD + fo + wn * 32];
-          fs[q][1] = Ac[kk * TLD + fo + wn * 32 + 16];
-        }
+      for (int e = 0; e < 4; ++e) {
+        mfma1(p, 0, e);
+        if (follows) stage_part(sn, e);
+        MAGMA_SB();
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SELF) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][0], fa[q][0], acc.c[0][0], 0, 0, 0);
-        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][0], fa[q][1], acc.c[0][1], 0, 0, 0);
-        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][1], fa[q][0], acc.c[1][0], 0, 0, 0);
-        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[q][1], fa[q][1], acc.c[1][1], 0, 0, 0);
-        if constexpr (SELF) {
-          accS.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][0], fa[q][0], accS.c[0][0], 0, 0, 0);
-          accS.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][0], fa[q][1], accS.c[0][1], 0, 0, 0);
-          accS.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][1], fa[q][0], accS.c[1][0], 0, 0, 0);
-          accS.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[q][1], fa[q][1], accS.c[1][1], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) mfmaS(p, 0, e);
+        MAGMA_SB();
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < 4) __syncthreads();
+      // group 1: this slab's groups 2 and 3 come out of LDS; the next tile's loads go out as this
+      // tile's registers come free
+      mfma1(p, 1, 0);
+      read_group(p, 2);
+      MAGMA_SB();
+      mfma1(p, 1, 1);
+      read_group(p, 3);
+      MAGMA_SB();
+      mfma1(p, 1, 2);
+      if (PF) {
+        if (s == 0) fetch_slab(k + 1, 0);
+        if (s == 1) fetch_slab(k + 1, 2);
+        if (s == 2) fetch_slab(k + 1, 3);
+      }
+      MAGMA_SB();
+      mfma1(p, 1, 3);
+      if (PF && s == 0) fetch_slab(k + 1, 1);
+      MAGMA_SB();
+      if constexpr (SELF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mfmaS(p, 1, e);
+        MAGMA_SB();
+      }
+      // group 2
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mfma1(p, 2, e);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mfmaS(p, 2, e);
+      MAGMA_SB();
+      // the next slab is visible, and every wavefront has read this one
+      if (follows) __syncthreads();
+      MAGMA_SB();
+      // group 3, with groups 0 and 1 of the next slab read under it
+      mfma1(p, 3, 0);
+      if (follows) read_group(p ^ 1, 0);
+      MAGMA_SB();
+      mfma1(p, 3, 1);
+      if (follows) read_group(p ^ 1, 1);
+      MAGMA_SB();
+      mfma1(p, 3, 2);
+      mfma1(p, 3, 3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mfmaS(p, 3, e);
+      MAGMA_SB();
     }
-    if (more && !pf) {
-      ready = poll_ready(fA, fB, k + 1, k1, ctrl, s_ready);
-      if (ready < 0) return false;
-      fetch(k + 1);
-    }
+  };
+  int k = k0;
+#pragma unroll 1
+  for (;;) {
+    // (slab 0 of tile k: loads issued) -> LDS, visible; its groups 0 and 1 in fragment set 0
+    __syncthreads();  // both buffers free (whatever read them last has passed this barrier)
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stage_part(0, part);
+    __syncthreads();
+    read_group(0, 0);
+    read_group(0, 1);
+    const int kf = (ready < k1 ? ready : k1) - 1;  // tiles k .. kf - 1 have a published successor
+#pragma unroll 1
+    for (; k < kf; ++k) tile(std::true_type{}, k);
+    tile(std::false_type{}, k);
+    ++k;
+    if (k >= k1) break;
+    ready = poll_ready(fA, fB, k, k1, ctrl, s_ready);
+    if (ready < 0) return false;
+    fetch(k);
   }
+#undef MAGMA_SB
   return true;
 }
 
