@@ -83,7 +83,7 @@ int magma_prof_reset(void);
  * magma_indiv_mstep_resident, status 6.
  * "dag_walker" (default 2): who walks the chain of diagonal tiles of the one-launch inverse -- 2: one
  * workgroup whose wavefronts work a block step ahead of the 64 x 64 factor, 1: one workgroup in
- * lock step, 0: a task per block step. "dag_max_block_rows" (default 64): the one-launch inverse
+ * lock step, 0: a task per block step. "dag_max_block_rows" (default 256): the one-launch inverse
  * is used up to this many 64-row blocks. Driver switches (default 1): "prefactor" (the M-step's
  * first K_0 inverse started next to the E-step's), "prefetch" (the next E-step's sums started
  * under the monitoring call; inside an EM iteration they start right behind the resident M-step

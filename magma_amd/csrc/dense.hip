@@ -925,7 +925,8 @@ int launch_se_cov_grid(int N, int Np, const double* grid, double th1, double th2
 
 size_t spd_inverse_workspace_doubles(int Np) { return 3 * (size_t)Np * Np; }
 
-// Panels per super-step of the launch-per-step inverse (N > 4,096); 1 = the plain right-looking form.
+// Panels per super-step of the launch-per-step inverse (dag_workgroups = 0, or more block rows
+// than dag_max_block_rows); 1 = the plain right-looking form.
 static std::atomic<int> g_panel_blocks{4};
 void set_panel_blocks(int v) { g_panel_blocks.store(v < 1 ? 1 : (v > 16 ? 16 : v)); }
 

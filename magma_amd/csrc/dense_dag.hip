@@ -1245,7 +1245,7 @@ void set_dag_stamps(void* p) { g_dag_stamps = static_cast<long long*>(p); }
 // The tile graph wins while the factorisation is latency bound (0.19 / 0.71 / 3.1 ms against
 // 0.29 / 1.18 / 3.4 ms at N = 500 / 2000 / 4000); from ~70 block rows on the launch-per-step
 // path's wide launches win (N = 6000: 7.2 against 10.6 ms, N = 8000: 14.9 against 19.8 ms).
-static int g_dag_max_block_rows = 64;
+static int g_dag_max_block_rows = 256;
 void set_dag_max_block_rows(int v) { g_dag_max_block_rows = v; }
 
 bool spd_inverse_dag_supported(int Np) {
