@@ -1242,9 +1242,11 @@ static long long* g_dag_stamps = nullptr;
 void set_dag_workgroups(int v) { g_dag_workgroups = v; }
 void set_dag_stamps(void* p) { g_dag_stamps = static_cast<long long*>(p); }
 
-// The tile graph wins while the factorisation is latency bound (0.19 / 0.71 / 3.1 ms against
-// 0.29 / 1.18 / 3.4 ms at N = 500 / 2000 / 4000); from ~70 block rows on the launch-per-step
-// path's wide launches win (N = 6000: 7.2 against 10.6 ms, N = 8000: 14.9 against 19.8 ms).
+// Round 2: the tile graph won while the factorisation was latency bound (N <= 4000) and lost to the
+// launch-per-step path's wide launches from ~70 block rows on (N = 8000: 19.8 against 14.9 ms).
+// With the pipelined tile products of round 3 (acc_rows_t) it wins at every size measured: N =
+// 2000 / 4000 / 6000 / 8000 / 16000: 0.50 / 1.71 / 5.36 / 10.65 / 79.7 ms (launch-per-step:
+// 1.15 / 3.4 / 7.4 / 14.7 ms). 256 block rows = N <= 16384.
 static int g_dag_max_block_rows = 256;
 void set_dag_max_block_rows(int v) { g_dag_max_block_rows = v; }
 
