@@ -109,6 +109,42 @@ def test_spd_inverse_and_logdet(gpu, inverse_path, N):
     assert np.abs(got - got.T).max() == 0.0  # mirrored store: exactly symmetric
 
 
+def test_tile_graph_inverse_beyond_64_block_rows(gpu):
+    """Round 3: the one-launch tile graph is the default at every size (it used to hand over to the
+    launch-per-step path above 64 block rows). N = 4700 = 74 block rows: against that path (same
+    Cholesky-based algorithm, other summation order) and against A A^-1 = I."""
+    torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
+    N = 4700
+    Np = lib.magma_pad(N)
+    st = _stream(torch)
+    g = torch.zeros(Np, dtype=torch.float64, device="cuda")
+    g[:N] = torch.linspace(0, 10, N, dtype=torch.float64)
+    A0 = torch.empty(Np * Np, dtype=torch.float64, device="cuda")
+    _lib.call("magma_kern_to_cov_grid", N, _p(g), 1.0, 1.0, 0.5, _p(A0), st)
+    work = torch.empty((lib.magma_workspace_bytes(N) + 7) // 8, dtype=torch.float64, device="cuda")
+    res = {}
+    try:
+        for name, wgs in (("graph", 256), ("launches", 0)):
+            _lib.call("magma_set_option", b"dag_workgroups", C.c_long(wgs))
+            A = A0.clone()
+            ld = torch.zeros(1, dtype=torch.float64, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _lib.call("magma_spd_inverse", N, _p(A), _p(ld), _p(info), _p(work), st)
+            torch.cuda.synchronize()
+            assert int(info.item()) == 0
+            res[name] = (A.view(Np, Np)[:N, :N].clone(), ld.item())
+    finally:
+        _lib.call("magma_set_option", b"dag_workgroups", C.c_long(256))
+    Ag, ldg = res["graph"]
+    Al, ldl = res["launches"]
+    K = A0.view(Np, Np)[:N, :N]
+    x = torch.randn(N, 4, dtype=torch.float64, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    assert (Ag @ (K @ x) - x).abs().max().item() < 1e-9
+    assert (Ag - Al).abs().max().item() < 1e-9 * Ag.abs().max().item()  # cond(K) ~ 1e4
+    assert abs(ldg - ldl) < 1e-9 * abs(ldg)
+    assert (Ag - Ag.T).abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("N,bad", [(70, 40), (300, 130)])
 def test_spd_inverse_flags_indefinite(gpu, inverse_path, N, bad):
     torch, lib, _lib = gpu["torch"], gpu["lib"], gpu["_lib"]
